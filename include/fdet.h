@@ -1,0 +1,209 @@
+/*
+ * fdet.h -- C-ABI of libfdet_hip.so: the MI355X (gfx950) hot path of a YOLO-style face
+ * detector (training step + inference), drop-in for the arithmetic behind the Python
+ * surface of smpurkis/PyTorch-Face-Detection-from-Scratch.
+ *
+ * The reference is pure Python and has no FFI of its own; each entry point below cites
+ * the reference function (path:line under /root/reference) or the third-party kernel the
+ * reference dispatches to that it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer (hipMalloc'd / torch-ROCm storage) unless the
+ *    parameter name starts with `h_`.  Tensors are dense, row-major, float32 unless noted;
+ *    feature maps are NCHW.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Every call only
+ *    enqueues work on that stream and returns; nothing synchronises, allocates or frees.
+ *    The caller owns all buffers, including workspaces (sizes via the *_ws_bytes helpers).
+ *  - Return value: 0 on success, negative FDET_E* on error (nothing is enqueued then);
+ *    fdet_last_error() returns a thread-local message.  Never throws across the boundary.
+ *  - No global mutable state: calls from different threads (e.g. the autograd worker) on
+ *    different streams are safe.
+ */
+#ifndef FDET_H
+#define FDET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDET_VERSION 100           /* 0.1.0 */
+#define FDET_OK 0
+#define FDET_EINVAL (-1)           /* bad argument / unsupported shape */
+#define FDET_ELAUNCH (-2)          /* hipLaunch failed (message holds hipGetErrorString) */
+#define FDET_EWORKSPACE (-3)       /* workspace too small */
+
+int fdet_version(void);
+const char* fdet_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Detection math (bit-exact integer/index work, fp32 within 1e-4)
+ * ------------------------------------------------------------------------------------- */
+
+/* Grid-cell target encode.  Replaces WIDERFaceDataset.convert_bbx_to_feature_map,
+ * datasets/WIDERFace/dataset.py:32-64, batched.
+ *   boxes      [total,5] rows [conf,x,y,w,h] (pixel units), images concatenated
+ *   box_offset [B+1] int32, image n owns rows box_offset[n] .. box_offset[n+1]-1
+ *   out        [B,5,S,S]; fully written (zeros where no box)
+ * Semantics kept: map dim1 indexes x; offsets use the UNCLAMPED cell index; cells are
+ * clamped to [0,S-1]; the LAST box written to a cell wins. */
+int fdet_encode_targets(const float* boxes, const int32_t* box_offset, int B, int S,
+                        float img_w, float img_h, float* out, void* stream);
+
+/* YOLO loss, forward + analytic backward in one pass.  Replaces losses/YoloLoss.py:4-44
+ * called per image and summed over the batch (models/ModelMeta.py:173-176) plus autograd.
+ *   pred, gt       [B,5,S,S]
+ *   loss_per_image [B]   (written)
+ *   loss_sum       [1]   (written; fixed-order sum of loss_per_image, deterministic)
+ *   grad_pred      [B,5,S,S] = grad_scale * d loss_sum / d pred, or NULL to skip
+ * Keeps: NaN->0.1 when nansum(pred_n)!=0 (:8-9), pred ch1/ch2 swap (:18), weights 3 and 1/S,
+ * the x**0.5 backward singularity (0*inf = NaN as autograd produces). */
+int fdet_yolo_loss_fwd_bwd(const float* pred, const float* gt, int B, int S,
+                           float* loss_per_image, float* loss_sum, float* grad_pred,
+                           float grad_scale, void* stream);
+
+/* Threshold + affine decode + xywh->xyxy + round-half-even.  Replaces
+ * ReduceBoundingBoxes.scale_batch_bbx_xywh / remove_low_probabilty_bbx /
+ * convert_batch_to_xyxy / torch.round, datasets/utils.py:111-126,152-155,162, batched.
+ *   maps   [B,5,S,S]
+ *   scores [B,S*S]      candidates in row-major (i,j) order of `x[0] > pt` (strict)
+ *   boxes  [B,S*S,4]    rounded x1,y1,x2,y2
+ *   counts [B] int32    number of candidates per image */
+int fdet_decode(const float* maps, int B, int S, float prob_threshold, float img_w, float img_h,
+                float* scores, float* boxes, int32_t* counts, void* stream);
+
+/* Greedy NMS, batched, one image per workgroup.  Replaces torchvision.ops.nms 0.11.2
+ * (call site datasets/utils.py:164).  Stable descending-score order; fp32 overlap compared
+ * against the double threshold; keep indices are returned in visiting order.
+ *   boxes [B,Kmax,4] xyxy, scores [B,Kmax], counts [B] (candidates per image, <= Kmax)
+ *   keep  [B,Kmax] int32 indices into the image's candidate list, keep_counts [B] int32
+ * Kmax <= 4096. */
+int fdet_nms(const float* boxes, const float* scores, const int32_t* counts, int B, int Kmax,
+             double iou_threshold, int32_t* keep, int32_t* keep_counts, void* stream);
+
+/* Fused ReduceBoundingBoxes.forward (datasets/utils.py:157-170) for a batch of maps:
+ * decode -> NMS -> gather -> xyxy->xywh.
+ *   out [B,S*S,5] rows [score,x,y,w,h] in keep order, out_counts [B] int32 */
+int fdet_reduce_bounding_boxes(const float* maps, int B, int S, float prob_threshold,
+                               double iou_threshold, float img_w, float img_h,
+                               float* out, int32_t* out_counts, void* stream);
+
+/* Step metrics.  Replaces the per-image block of ModelMeta.step, models/ModelMeta.py:199-214
+ * (torchvision.ops.box_iou + counts), given the reduced boxes of targets and predictions.
+ *   gt/pred [B,Kmax,5] rows [score,x,y,w,h], gt_counts/pred_counts [B]
+ *   per_image [B,3]  (sum IoU, recall, precision) for each image (0 when no prediction)
+ *   totals    [3]    fixed-order sums over the batch divided by B (:216-218) */
+int fdet_step_metrics(const float* gt, const int32_t* gt_counts, const float* pred,
+                      const int32_t* pred_counts, int B, int Kmax, float* per_image,
+                      float* totals, void* stream);
+
+/* uint8 -> float32 / 255 (true division).  Replaces `resize(x) / 255.0`,
+ * models/PoolResnet.py:95, for inputs already at the model resolution (Resize is then the
+ * identity round trip) and `img / 255`, datasets/WIDERFace/dataset.py:146. */
+int fdet_u8_to_f32_norm(const uint8_t* in, float* out, size_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimiser
+ * ------------------------------------------------------------------------------------- */
+
+/* Adam on one flat parameter buffer.  Replaces torch.optim._multi_tensor.Adam.step reached
+ * through SAMSGD.step, models/ModelMeta.py:12,81 (lr 1e-4, betas .9/.999, eps 1e-8, wd 0).
+ * `step` is 1-based.  Hyper-parameters are doubles (Python floats in the reference; bias
+ * corrections are formed in double and rounded once).  grad_scale multiplies the gradient
+ * first (1.0 normally). */
+int fdet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                   int step, double lr, double beta1, double beta2, double eps, float grad_scale,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Conv stack (PoolResnet / Resnet): fp32 implicit GEMM on v_mfma_f32_32x32x2_f32
+ * ------------------------------------------------------------------------------------- */
+
+/* Repack OIHW 3x3 weights [Cout,Cin,3,3] into the two K-major panels the conv kernels read:
+ *   wpk_fwd [Cin*9][CoutP]  k=(ci,tap)          A panel of the forward conv
+ *   wpk_bwd [Cout*9][CinP]  k=(co,flipped tap)  A panel of the data-gradient conv
+ * CoutP/CinP = channel count rounded up to 32 (zero padded).  Either output may be NULL. */
+int fdet_pack_conv3x3_weights(const float* w, int Cout, int Cin, float* wpk_fwd, float* wpk_bwd,
+                              void* stream);
+
+/* 3x3 stride-1 pad-1 convolution with fused tail.  Replaces nn.Conv2d + LeakyReLU(0.2)
+ * [+ Dropout2d + skip add + MaxPool2d(2)] of ResidualBlock.forward,
+ * models/PoolResnet.py:33-43 (models/Resnet.py:30-40).
+ *   x [N,Cin,H,W], wpk = wpk_fwd of fdet_pack_conv3x3_weights, bias [Cout]
+ *   z = lrelu(conv(x)+bias, slope)
+ *   y_full [N,Cout,H,W]  = z                         (NULL to skip; saved for backward)
+ *   y_out  [N,Cout,H,W] = z*drop_scale[n,c] + skip      (NULL to skip; un-pooled tail)
+ *   skip [N,Cout,H,W] or NULL; drop_scale [N,Cout] or NULL (eval).
+ * `pool` must be 1: blocks that pool write y_full here and finish in fdet_block_tail_fwd. */
+int fdet_conv3x3_fwd(const float* x, const float* wpk, const float* bias, float* y_full,
+                     const float* skip, const float* drop_scale, float* y_out,
+                     int N, int Cin, int Cout, int H, int W, int pool, float slope, void* stream);
+
+/* Data gradient of the 3x3 conv with fused tail (autograd of the above):
+ *   dx = conv_transpose(dz) * lrelu'(act) + add
+ *   dz [N,Cout,H,W], wpk = wpk_bwd, act [N,Cin,H,W] or NULL (lrelu'(a)=1 if a>0 else slope),
+ *   add [N,Cin,H,W] or NULL, dx [N,Cin,H,W]. */
+int fdet_conv3x3_dgrad(const float* dz, const float* wpk, const float* act, const float* add,
+                       float* dx, int N, int Cin, int Cout, int H, int W, float slope, void* stream);
+
+/* Weight + bias gradient of the 3x3 conv: dW[co,ci,ky,kx] = sum_{n,y,x} dz*x_shifted,
+ * db[co] = sum dz.  Deterministic two-pass (per-workgroup slabs in `ws`, then a fixed-order
+ * reduce).  dW [Cout,Cin,3,3], db [Cout] are overwritten. */
+size_t fdet_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int fdet_conv3x3_wgrad(const float* x, const float* dz, float* dW, float* db, void* ws,
+                       size_t ws_bytes, int N, int Cin, int Cout, int H, int W, void* stream);
+
+/* Residual-block tail for pooled blocks: out = maxpool_pool(c*drop_scale[n,f] + x)
+ * (Dropout2d + skip add + MaxPool2d(2), models/PoolResnet.py:39-42).  pool in {1,2}.
+ *   c,x [N,F,H,W]; drop_scale [N,F] or NULL; out [N,F,H/pool,W/pool]. */
+int fdet_block_tail_fwd(const float* c, const float* x, const float* drop_scale, float* out,
+                        int N, int F, int H, int W, int pool, void* stream);
+
+/* Backward of the residual-block tail (dropout, skip, max-pool, second LeakyReLU):
+ *   e = c*drop_scale + x ; out = maxpool(e) ; given dout [N,F,H/pool,W/pool]:
+ *   de = unpool(dout) (first max in window scan order wins, as ATen max_pool2d backward)
+ *   dz2 = de * drop_scale * lrelu'(c)
+ *   c,x [N,F,H,W]; dz2 [N,F,H,W]; de [N,F,H,W] written only if pool==2 (else de==dout, may be NULL). */
+int fdet_block_tail_bwd(const float* dout, const float* c, const float* x, const float* drop_scale,
+                        float* dz2, float* de, int N, int F, int H, int W, int pool, float slope,
+                        void* stream);
+
+/* Stem convolution (no activation).  Replaces nn.Conv2d(3,F,k,stride,pad) of
+ * models/PoolResnet.py:70-76,98 (k10 s8 p2) and models/Resnet.py:64-70 (k3 s2 p1); other
+ * (k,stride,pad) return FDET_EINVAL.
+ *   x [N,Cin,H,W], w [F,Cin,k,k] (OIHW), bias [F], y [N,F,Ho,Wo].
+ * `ws` (fdet_stem_ws_bytes) holds the K-major weight panel the kernel reads (rebuilt per
+ * call) and, for the weight gradient, the per-workgroup slabs of the fixed-order reduction. */
+size_t fdet_stem_ws_bytes(int N, int Cin, int F, int H, int W, int k, int stride, int pad);
+int fdet_stem_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                  int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream);
+/* dW [F,Cin,k,k], db [F] from x and dy [N,F,Ho,Wo] (autograd of the stem; the input image
+ * needs no gradient, so there is no data-gradient entry point). */
+int fdet_stem_wgrad(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,
+                    int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream);
+
+/* Head: Dropout2d(0.5) + Conv2d(F,5,k,pad) + Sigmoid.  Replaces models/PoolResnet.py:100-102
+ * (k6 p0) and models/Resnet.py:94-96 (k3 p1).
+ *   x [N,F,H,W], drop_scale [N,F] or NULL, w [5,F,k,k], bias [5], y [N,5,S,S] (post-sigmoid). */
+int fdet_head_fwd(const float* x, const float* drop_scale, const float* w, const float* bias,
+                  float* y, int N, int F, int H, int W, int k, int pad, void* stream);
+/* Backward of the head given dy = d loss / d y (post-sigmoid):
+ *   dx [N,F,H,W] (includes drop_scale), dW [5,F,k,k], db [5]. */
+size_t fdet_head_bwd_ws_bytes(int N, int F, int H, int W, int k, int pad);
+int fdet_head_bwd(const float* x, const float* drop_scale, const float* w, const float* y,
+                  const float* dy, float* dx, float* dW, float* db, void* ws, size_t ws_bytes,
+                  int N, int F, int H, int W, int k, int pad, void* stream);
+
+/* Dropout2d scale factors: out[i] = (u_i >= p) ? 1/(1-p) : 0 with u from a counter-based
+ * generator keyed by (seed, offset+i).  Replaces nn.Dropout2d's per-(n,c) Bernoulli draw
+ * (models/PoolResnet.py:31,69).  The stream differs from ATen's Philox usage, so parity
+ * tests inject masks instead. */
+int fdet_dropout_scales(float* out, size_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDET_H */

@@ -1,0 +1,436 @@
+// Detection math of the hot path: target encode, YOLO loss fwd+bwd, decode, greedy NMS,
+// step metrics, u8 normalise.  Built with -ffp-contract=off: decode / NMS / IoU results are
+// compared BIT-EXACTLY with the reference's CPU arithmetic (separate mul and add, IEEE
+// division), so no FMA contraction is allowed in this file.
+#include "fdet_common.h"
+#include <cfloat>
+#include <cmath>
+
+using namespace fdet;
+
+// ======================================================================================
+// encode -- datasets/WIDERFace/dataset.py:32-64
+// ======================================================================================
+__global__ void __launch_bounds__(256)
+k_encode(const float* __restrict__ boxes, const int32_t* __restrict__ off, int S,
+         double ps_x, double ps_y, float fw, float fh, float* __restrict__ out) {
+  const int n = blockIdx.x;
+  float* fm = out + (size_t)n * 5 * S * S;
+  const int cells = 5 * S * S;
+  for (int t = threadIdx.x; t < cells; t += blockDim.x) fm[t] = 0.f;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const float psx = (float)ps_x, psy = (float)ps_y;
+  const int b0 = off[n], b1 = off[n + 1];
+  for (int k = b0; k < b1; ++k) {          // in order: later boxes overwrite (dataset.py:63)
+    const float* bx = boxes + (size_t)k * 5;
+    const float c = bx[0], x = bx[1], y = bx[2], w = bx[3], h = bx[4];
+    float qi = floorf(x / psx), qj = floorf(y / psy);                 // :43
+    qi = fminf(fmaxf(qi, -1.0e9f), 1.0e9f);
+    qj = fminf(fmaxf(qj, -1.0e9f), 1.0e9f);
+    int i = (int)qi, j = (int)qj;
+    // :51-52  tensor - python_float(i*ps): the scalar is rounded to fp32 first
+    const float ox = (x - (float)((double)i * ps_x)) / psx;          // :55
+    const float oy = (y - (float)((double)j * ps_y)) / psy;          // :56
+    const float wn = w / fw, hn = h / fh;                             // :58-59
+    i = min(max(i, 0), S - 1);                                        // :61
+    j = min(max(j, 0), S - 1);                                        // :62
+    const int cell = i * S + j;
+    fm[0 * S * S + cell] = c;
+    fm[1 * S * S + cell] = ox;
+    fm[2 * S * S + cell] = oy;
+    fm[3 * S * S + cell] = wn;
+    fm[4 * S * S + cell] = hn;
+  }
+}
+
+extern "C" int fdet_encode_targets(const float* boxes, const int32_t* box_offset, int B, int S,
+                                   float img_w, float img_h, float* out, void* stream) {
+  FDET_REQUIRE(B >= 0 && S > 0 && out && box_offset, "encode: bad arguments (B=%d S=%d)", B, S);
+  if (B == 0) return FDET_OK;
+  hipLaunchKernelGGL(k_encode, dim3(B), dim3(256), 0, (hipStream_t)stream, boxes, box_offset, S,
+                     (double)img_w / S, (double)img_h / S, img_w, img_h, out);
+  return check_launch("fdet_encode_targets");
+}
+
+// ======================================================================================
+// loss fwd + bwd -- losses/YoloLoss.py:4-44, models/ModelMeta.py:173-176
+// one wavefront per image; wave-shuffle reduction of the per-cell loss
+// ======================================================================================
+__global__ void __launch_bounds__(64)
+k_yolo_loss(const float* __restrict__ pred, const float* __restrict__ gt, int S,
+            float* __restrict__ loss_per_image, float* __restrict__ grad, float grad_scale) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int C = S * S;
+  const float* p = pred + (size_t)n * 5 * C;
+  const float* g = gt + (size_t)n * 5 * C;
+  // :8  torch.nansum(pred) != 0 decides whether nan_to_num runs
+  float ns = 0.f;
+  for (int t = lane; t < 5 * C; t += 64) { float v = p[t]; ns += (v == v) ? v : 0.f; }
+  ns = wave_sum_all(ns);
+  const bool fix = (ns != 0.f);           // NaN nansum cannot happen; +-inf != 0 is true
+  const float inv_s = (float)(1.0 / (double)S);                       // :25
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    float pv[5], fin[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      float v = p[k * C + c];
+      fin[k] = 1.f;
+      if (fix) {                                                      // :9 nan_to_num(nan=0.1)
+        fin[k] = (isfinite(v)) ? 1.f : 0.f;
+        if (v != v) v = 0.1f;
+        else if (isinf(v)) v = (v > 0.f) ? FLT_MAX : -FLT_MAX;
+      }
+      pv[k] = v;
+    }
+    const float g0 = g[c], g1 = g[C + c], g2 = g[2 * C + c], g3 = g[3 * C + c], g4 = g[4 * C + c];
+    const float obj = g0, noobj = 1.f - g0;                           // :22-23
+    const float dx = g1 - pv[2], dy = g2 - pv[1];                     // :18 pred y,x = ch1,ch2
+    const float sg3 = sqrtf(g3), sp3 = sqrtf(pv[3]), sg4 = sqrtf(g4), sp4 = sqrtf(pv[4]);
+    const float dw = sg3 - sp3, dh = sg4 - sp4;
+    const float cw = 3.f * obj;                                       // :24
+    const float xy = cw * (dx * dx + dy * dy);                        // :27-29
+    const float wh = cw * (dw * dw + dh * dh);                        // :30-34
+    const float wconf = obj + noobj * inv_s;
+    const float dc = g0 - pv[0];
+    const float conf = wconf * (dc * dc);                             // :36-38
+    acc += xy + wh + conf;                                            // :40
+    if (grad) {
+      float d[5];
+      d[0] = wconf * (2.f * dc) * -1.f;
+      d[1] = cw * (2.f * dy) * -1.f;
+      d[2] = cw * (2.f * dx) * -1.f;
+      // autograd of x**0.5: grad * 0.5 * x**(-0.5); 0*inf = NaN is reproduced on purpose (Q8)
+      d[3] = (cw * (2.f * dw) * -1.f) * (0.5f * (1.f / sp3));
+      d[4] = (cw * (2.f * dh) * -1.f) * (0.5f * (1.f / sp4));
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        float v = d[k];
+        if (fix) v = v * fin[k];          // nan_to_num backward: grad * isfinite(input)
+        grad[(size_t)n * 5 * C + k * C + c] = v * grad_scale;
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) loss_per_image[n] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_sum_fixed(const float* __restrict__ v, int n, float scale, float* __restrict__ out) {
+  __shared__ float part[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = part[0] * scale;
+}
+
+extern "C" int fdet_yolo_loss_fwd_bwd(const float* pred, const float* gt, int B, int S,
+                                      float* loss_per_image, float* loss_sum, float* grad_pred,
+                                      float grad_scale, void* stream) {
+  FDET_REQUIRE(B > 0 && S > 0 && pred && gt && loss_per_image, "yolo_loss: bad arguments");
+  hipLaunchKernelGGL(k_yolo_loss, dim3(B), dim3(64), 0, (hipStream_t)stream, pred, gt, S,
+                     loss_per_image, grad_pred, grad_scale);
+  if (loss_sum)
+    hipLaunchKernelGGL(k_sum_fixed, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_per_image, B, 1.0f,
+                       loss_sum);
+  return check_launch("fdet_yolo_loss_fwd_bwd");
+}
+
+// ======================================================================================
+// decode + NMS -- datasets/utils.py:95-170, torchvision.ops.nms 0.11.2 (CPU kernel)
+// One workgroup per image; candidates live in LDS.
+// ======================================================================================
+struct NmsLds {
+  float* x1; float* y1; float* x2; float* y2; float* score; float* area;
+  int* order;            // sorted position -> candidate index
+  unsigned char* dead;   // by sorted position
+};
+
+__device__ __forceinline__ NmsLds carve(char* smem, int Kmax) {
+  NmsLds L;
+  float* f = reinterpret_cast<float*>(smem);
+  L.x1 = f; L.y1 = f + Kmax; L.x2 = f + 2 * Kmax; L.y2 = f + 3 * Kmax;
+  L.score = f + 4 * Kmax; L.area = f + 5 * Kmax;
+  L.order = reinterpret_cast<int*>(f + 6 * Kmax);
+  L.dead = reinterpret_cast<unsigned char*>(f + 7 * Kmax);
+  return L;
+}
+__host__ __device__ static inline size_t nms_lds_bytes(int Kmax) { return (size_t)Kmax * 7 * 4 + (size_t)((Kmax + 15) / 16) * 16 + 64; }
+
+// Block-wide ordered compaction of the cells with conf > pt; writes candidates (raw, in
+// row-major (i,j) order) into L.* and returns K.  utils.py:111-126,152-155,162.
+__device__ int decode_to_lds(const float* __restrict__ m, int S, float pt, float psx, float psy,
+                             float fw, float fh, NmsLds L, int* s_base /*LDS [1+nwaves]*/) {
+  const int C = S * S;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  if (tid == 0) s_base[0] = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < C; c0 += blockDim.x) {
+    const int c = c0 + tid;
+    const bool hit = (c < C) && (m[c] > pt);                          // strict > (:112,:119)
+    const unsigned long long bal = __ballot(hit);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_base[1 + wid] = __popcll(bal);
+    __syncthreads();
+    int base = s_base[0];
+    for (int w = 0; w < wid; ++w) base += s_base[1 + w];
+    if (hit) {
+      const int k = base + before;
+      const int i = c / S, j = c - i * S;
+      const float X = m[C + c] * psx + (float)i * psx;               // :122 two mults + add
+      const float Y = m[2 * C + c] * psy + (float)j * psy;           // :123
+      const float Wp = m[3 * C + c] * fw;                            // :124
+      const float Hp = m[4 * C + c] * fh;                            // :125
+      const float X2 = Wp + X, Y2 = Hp + Y;                          // :153-154
+      L.score[k] = m[c];
+      L.x1[k] = rintf(X); L.y1[k] = rintf(Y); L.x2[k] = rintf(X2); L.y2[k] = rintf(Y2);   // :162
+    }
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < nw; ++w) t += s_base[1 + w]; s_base[0] += t; }
+    __syncthreads();
+  }
+  return s_base[0];
+}
+
+// Greedy NMS over the K candidates in L (torchvision 0.11.2 nms_kernel.cpp).  On return
+// keep_pos[0..nkeep) holds candidate indices in visiting order (LDS).  Returns nkeep.
+__device__ int nms_lds(NmsLds L, int K, double thr, int* keep_idx, int* s_cnt) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // stable descending sort by rank counting: rank = #{j : s_j > s_i or (s_j == s_i and j < i)}
+  for (int i = tid; i < K; i += nt) {
+    const float si = L.score[i];
+    int r = 0;
+    for (int j = 0; j < K; ++j) { const float sj = L.score[j]; r += (sj > si) || (sj == si && j < i); }
+    L.order[r] = i;
+    L.area[i] = (L.x2[i] - L.x1[i]) * (L.y2[i] - L.y1[i]);
+  }
+  for (int i = tid; i < K; i += nt) L.dead[i] = 0;
+  if (tid == 0) s_cnt[0] = 0;
+  __syncthreads();
+  for (int a = 0; a < K; ++a) {
+    if (L.dead[a]) continue;                 // uniform: written before the last barrier
+    const int i = L.order[a];
+    if (tid == 0) { keep_idx[s_cnt[0]] = i; s_cnt[0] += 1; }
+    const float ix1 = L.x1[i], iy1 = L.y1[i], ix2 = L.x2[i], iy2 = L.y2[i], ia = L.area[i];
+    for (int b = a + 1 + tid; b < K; b += nt) {
+      if (L.dead[b]) continue;
+      const int j = L.order[b];
+      const float w = fmaxf(0.f, fminf(ix2, L.x2[j]) - fmaxf(ix1, L.x1[j]));
+      const float h = fmaxf(0.f, fminf(iy2, L.y2[j]) - fmaxf(iy1, L.y1[j]));
+      const float inter = w * h;
+      const float ovr = inter / (ia + L.area[j] - inter);           // 0/0 = NaN -> not suppressed
+      if ((double)ovr > thr) L.dead[b] = 1;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  return s_cnt[0];
+}
+
+__global__ void __launch_bounds__(256)
+k_decode(const float* __restrict__ maps, int S, float pt, float psx, float psy, float fw, float fh,
+         float* __restrict__ scores, float* __restrict__ boxes, int32_t* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = blockIdx.x, C = S * S;
+  NmsLds L = carve(smem, C);
+  int* s_base = reinterpret_cast<int*>(smem + nms_lds_bytes(C) - 64);
+  const int K = decode_to_lds(maps + (size_t)n * 5 * C, S, pt, psx, psy, fw, fh, L, s_base);
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    scores[(size_t)n * C + k] = L.score[k];
+    float* b = boxes + ((size_t)n * C + k) * 4;
+    b[0] = L.x1[k]; b[1] = L.y1[k]; b[2] = L.x2[k]; b[3] = L.y2[k];
+  }
+  if (threadIdx.x == 0) counts[n] = K;
+}
+
+__global__ void __launch_bounds__(256)
+k_nms(const float* __restrict__ boxes, const float* __restrict__ scores, const int32_t* __restrict__ counts,
+      int Kmax, double thr, int32_t* __restrict__ keep, int32_t* __restrict__ keep_counts) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = blockIdx.x;
+  NmsLds L = carve(smem, Kmax);
+  int* s_cnt = reinterpret_cast<int*>(smem + nms_lds_bytes(Kmax) - 64);
+  int* keep_idx = reinterpret_cast<int*>(smem + nms_lds_bytes(Kmax));
+  const int K = min(max(counts[n], 0), Kmax);
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float* b = boxes + ((size_t)n * Kmax + k) * 4;
+    L.x1[k] = b[0]; L.y1[k] = b[1]; L.x2[k] = b[2]; L.y2[k] = b[3];
+    L.score[k] = scores[(size_t)n * Kmax + k];
+  }
+  __syncthreads();
+  const int nk = nms_lds(L, K, thr, keep_idx, s_cnt);
+  for (int k = threadIdx.x; k < nk; k += blockDim.x) keep[(size_t)n * Kmax + k] = keep_idx[k];
+  if (threadIdx.x == 0) keep_counts[n] = nk;
+}
+
+__global__ void __launch_bounds__(256)
+k_reduce_bbx(const float* __restrict__ maps, int S, float pt, double thr, float psx, float psy, float fw,
+             float fh, float* __restrict__ out, int32_t* __restrict__ out_counts) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = blockIdx.x, C = S * S;
+  NmsLds L = carve(smem, C);
+  int* s_base = reinterpret_cast<int*>(smem + nms_lds_bytes(C) - 64);
+  int* keep_idx = reinterpret_cast<int*>(smem + nms_lds_bytes(C));
+  const int K = decode_to_lds(maps + (size_t)n * 5 * C, S, pt, psx, psy, fw, fh, L, s_base);
+  __syncthreads();
+  const int nk = nms_lds(L, K, thr, keep_idx, s_base);
+  for (int k = threadIdx.x; k < nk; k += blockDim.x) {
+    const int i = keep_idx[k];
+    float* o = out + ((size_t)n * C + k) * 5;
+    o[0] = L.score[i]; o[1] = L.x1[i]; o[2] = L.y1[i];
+    o[3] = L.x2[i] - L.x1[i];                                        // utils.py:148
+    o[4] = L.y2[i] - L.y1[i];                                        // utils.py:149
+  }
+  if (threadIdx.x == 0) out_counts[n] = nk;
+}
+
+template <typename Kern>
+static int set_lds(Kern kern, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(FDET_ELAUNCH, "hipFuncSetAttribute(%zu): %s", bytes, hipGetErrorString(e));
+  }
+  return FDET_OK;
+}
+
+extern "C" int fdet_decode(const float* maps, int B, int S, float prob_threshold, float img_w, float img_h,
+                           float* scores, float* boxes, int32_t* counts, void* stream) {
+  FDET_REQUIRE(B > 0 && S > 0 && S * S <= 4096 && maps && scores && boxes && counts, "decode: bad arguments");
+  const size_t lds = nms_lds_bytes(S * S);
+  if (int rc = set_lds(k_decode, lds)) return rc;
+  const float psx = (float)((double)img_w / S), psy = (float)((double)img_h / S);
+  hipLaunchKernelGGL(k_decode, dim3(B), dim3(256), lds, (hipStream_t)stream, maps, S, prob_threshold, psx,
+                     psy, img_w, img_h, scores, boxes, counts);
+  return check_launch("fdet_decode");
+}
+
+extern "C" int fdet_nms(const float* boxes, const float* scores, const int32_t* counts, int B, int Kmax,
+                        double iou_threshold, int32_t* keep, int32_t* keep_counts, void* stream) {
+  FDET_REQUIRE(B > 0 && Kmax > 0 && Kmax <= 4096 && boxes && scores && counts && keep && keep_counts,
+               "nms: bad arguments (Kmax=%d must be in 1..4096)", Kmax);
+  const size_t lds = nms_lds_bytes(Kmax) + (size_t)Kmax * 4;
+  if (int rc = set_lds(k_nms, lds)) return rc;
+  hipLaunchKernelGGL(k_nms, dim3(B), dim3(256), lds, (hipStream_t)stream, boxes, scores, counts, Kmax,
+                     iou_threshold, keep, keep_counts);
+  return check_launch("fdet_nms");
+}
+
+extern "C" int fdet_reduce_bounding_boxes(const float* maps, int B, int S, float prob_threshold,
+                                          double iou_threshold, float img_w, float img_h, float* out,
+                                          int32_t* out_counts, void* stream) {
+  FDET_REQUIRE(B > 0 && S > 0 && S * S <= 4096 && maps && out && out_counts, "reduce_bounding_boxes: bad arguments");
+  const size_t lds = nms_lds_bytes(S * S) + (size_t)S * S * 4;
+  if (int rc = set_lds(k_reduce_bbx, lds)) return rc;
+  const float psx = (float)((double)img_w / S), psy = (float)((double)img_h / S);
+  hipLaunchKernelGGL(k_reduce_bbx, dim3(B), dim3(256), lds, (hipStream_t)stream, maps, S, prob_threshold,
+                     iou_threshold, psx, psy, img_w, img_h, out, out_counts);
+  return check_launch("fdet_reduce_bounding_boxes");
+}
+
+// ======================================================================================
+// step metrics -- models/ModelMeta.py:199-218 with torchvision.ops.box_iou 0.11.2
+// ======================================================================================
+__global__ void __launch_bounds__(64)
+k_metrics(const float* __restrict__ gt, const int32_t* __restrict__ gtc, const float* __restrict__ pr,
+          const int32_t* __restrict__ prc, int Kmax, float* __restrict__ per_image) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int G = gtc[n], P = prc[n];
+  float iou_sum = 0.f; int hits = 0;
+  if (P > 0) {                                                        // :199
+    for (int t = lane; t < G * P; t += 64) {
+      const int a = t / P, b = t - a * P;
+      const float* ga = gt + ((size_t)n * Kmax + a) * 5;
+      const float* pb = pr + ((size_t)n * Kmax + b) * 5;
+      const float gx1 = ga[1], gy1 = ga[2], gx2 = ga[3] + ga[1], gy2 = ga[4] + ga[2];   // :201-202
+      const float px1 = pb[1], py1 = pb[2], px2 = pb[3] + pb[1], py2 = pb[4] + pb[2];   // :204-205
+      const float a1 = (gx2 - gx1) * (gy2 - gy1), a2 = (px2 - px1) * (py2 - py1);
+      const float w = fmaxf(fminf(gx2, px2) - fmaxf(gx1, px1), 0.f);
+      const float h = fmaxf(fminf(gy2, py2) - fmaxf(gy1, py1), 0.f);
+      const float inter = w * h;
+      float iou = inter / (a1 + a2 - inter);
+      if (iou != iou) iou = 0.f;                                      // nan_to_num(.,0) :206
+      else if (isinf(iou)) iou = iou > 0.f ? FLT_MAX : -FLT_MAX;
+      hits += (iou > 0.5f);
+      iou_sum += iou;
+    }
+  }
+  iou_sum = wave_sum(iou_sum);
+  float fh = wave_sum((float)hits);
+  if (lane == 0) {
+    float recall = 0.f, precision = 0.f;
+    if (P > 0) {
+      recall = (G == 0) ? 0.f : (float)((double)fh / (double)G);      // :207-210
+      precision = (float)((double)fh / (double)P);                    // :212
+    }
+    per_image[n * 3 + 0] = iou_sum;
+    per_image[n * 3 + 1] = recall;
+    per_image[n * 3 + 2] = precision;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_metrics_total(const float* __restrict__ per_image, int B, float* __restrict__ totals) {
+  const int lane = threadIdx.x;
+  if (lane < 3) {
+    double s = 0.0;
+    for (int n = 0; n < B; ++n) s += (double)per_image[n * 3 + lane];
+    totals[lane] = (float)(s / (double)B);                            // :216-218
+  }
+}
+
+extern "C" int fdet_step_metrics(const float* gt, const int32_t* gt_counts, const float* pred,
+                                 const int32_t* pred_counts, int B, int Kmax, float* per_image,
+                                 float* totals, void* stream) {
+  FDET_REQUIRE(B > 0 && Kmax > 0 && gt && pred && gt_counts && pred_counts && per_image, "step_metrics: bad arguments");
+  hipLaunchKernelGGL(k_metrics, dim3(B), dim3(64), 0, (hipStream_t)stream, gt, gt_counts, pred, pred_counts,
+                     Kmax, per_image);
+  if (totals)
+    hipLaunchKernelGGL(k_metrics_total, dim3(1), dim3(64), 0, (hipStream_t)stream, per_image, B, totals);
+  return check_launch("fdet_step_metrics");
+}
+
+// ======================================================================================
+// u8 -> f32 / 255 -- models/PoolResnet.py:95, datasets/WIDERFace/dataset.py:146
+// ======================================================================================
+__global__ void __launch_bounds__(256)
+k_u8_norm(const uint8_t* __restrict__ in, float* __restrict__ out, size_t n) {
+  const size_t nv = n / 16;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
+    const uint4 q = reinterpret_cast<const uint4*>(in)[v];
+    const unsigned wv[4] = {q.x, q.y, q.z, q.w};
+    float4* o = reinterpret_cast<float4*>(out) + v * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 f;
+      f.x = (float)(wv[k] & 255u) / 255.0f;
+      f.y = (float)((wv[k] >> 8) & 255u) / 255.0f;
+      f.z = (float)((wv[k] >> 16) & 255u) / 255.0f;
+      f.w = (float)(wv[k] >> 24) / 255.0f;
+      o[k] = f;
+    }
+  }
+  if (blockIdx.x == 0)
+    for (size_t t = nv * 16 + threadIdx.x; t < n; t += blockDim.x) out[t] = (float)in[t] / 255.0f;
+}
+
+extern "C" int fdet_u8_to_f32_norm(const uint8_t* in, float* out, size_t n, void* stream) {
+  FDET_REQUIRE(in && out, "u8_to_f32_norm: null pointer");
+  FDET_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "u8_to_f32_norm: pointers must be 16-byte aligned");
+  if (n == 0) return FDET_OK;
+  size_t blocks = (n / 16 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_u8_norm, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, n);
+  return check_launch("fdet_u8_to_f32_norm");
+}
+
+extern "C" int fdet_version(void) { return FDET_VERSION; }
+extern "C" const char* fdet_last_error(void) { return fdet::err_buf(); }

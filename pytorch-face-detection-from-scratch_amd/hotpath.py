@@ -1,0 +1,293 @@
+"""Tensor-level wrappers over the C-ABI (include/fdet.h).  Each function validates shapes on
+the host (a kernel launched on mismatched shapes can fault the GPU), allocates the outputs
+with torch, and enqueues the HIP kernels on torch's current stream.  GPU tensors only.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+from ._native import check, lib, ptr, stream
+
+I32 = torch.int32
+F32 = torch.float32
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != F32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+# detection math
+# ------------------------------------------------------------------------------------------
+def encode_targets(boxes: Sequence[torch.Tensor], img_size: Tuple[int, int], num_of_patches: int,
+                   device=None) -> torch.Tensor:
+    """Batched WIDERFaceDataset.convert_bbx_to_feature_map (dataset.py:32-64).
+    `boxes`: list of (n_i,5) tensors [conf,x,y,w,h] -> (B,5,S,S) on the GPU."""
+    B = len(boxes)
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    counts = [int(b.shape[0]) if b.numel() else 0 for b in boxes]
+    offs = torch.zeros(B + 1, dtype=I32)
+    offs[1:] = torch.cumsum(torch.tensor(counts, dtype=torch.int64), 0).to(I32)
+    rows = [b.reshape(-1, 5).to(F32).cpu() for b in boxes if b.numel()]
+    flat = torch.cat(rows, 0) if rows else torch.zeros(1, 5)
+    flat_d = flat.contiguous().to(device)
+    offs_d = offs.to(device)
+    S = int(num_of_patches)
+    out = torch.empty(B, 5, S, S, dtype=F32, device=device)
+    if B:
+        check(lib().fdet_encode_targets(ptr(flat_d), ptr(offs_d, I32), B, S, float(img_size[0]), float(img_size[1]),
+                                        ptr(out), stream()), "fdet_encode_targets")
+    return out
+
+
+def yolo_loss_fwd_bwd(pred: torch.Tensor, gt: torch.Tensor, want_grad: bool = True, grad_scale: float = 1.0):
+    """(B,5,S,S) x2 -> (loss_per_image (B,), loss_sum (1,), grad (B,5,S,S) or None)."""
+    pred, gt = _f32(pred), _f32(gt)
+    if pred.dim() != 4 or pred.shape[1] != 5 or pred.shape[2] != pred.shape[3] or pred.shape != gt.shape:
+        raise ValueError(f"yolo_loss: expected matching (B,5,S,S) maps, got {tuple(pred.shape)} / {tuple(gt.shape)}")
+    B, _, S, _ = pred.shape
+    lpi = torch.empty(B, dtype=F32, device=pred.device)
+    lsum = torch.empty(1, dtype=F32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    check(lib().fdet_yolo_loss_fwd_bwd(ptr(pred), ptr(gt), B, S, ptr(lpi), ptr(lsum), ptr(grad), float(grad_scale),
+                                       stream()), "fdet_yolo_loss_fwd_bwd")
+    return lpi, lsum, grad
+
+
+def decode(maps: torch.Tensor, prob_threshold: float, img_w: float, img_h: float):
+    maps = _f32(maps)
+    B, C, S, S2 = maps.shape
+    if C != 5 or S != S2:
+        raise ValueError(f"decode: expected (B,5,S,S), got {tuple(maps.shape)}")
+    scores = torch.zeros(B, S * S, dtype=F32, device=maps.device)
+    boxes = torch.zeros(B, S * S, 4, dtype=F32, device=maps.device)
+    counts = torch.zeros(B, dtype=I32, device=maps.device)
+    check(lib().fdet_decode(ptr(maps), B, S, float(prob_threshold), float(img_w), float(img_h), ptr(scores),
+                            ptr(boxes), ptr(counts, I32), stream()), "fdet_decode")
+    return scores, boxes, counts
+
+
+def nms_batched(boxes: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor, iou_threshold: float):
+    boxes, scores = _f32(boxes), _f32(scores)
+    B, K, four = boxes.shape
+    if four != 4 or scores.shape != (B, K) or counts.shape != (B,):
+        raise ValueError("nms_batched: expected boxes (B,K,4), scores (B,K), counts (B,)")
+    counts = counts.to(I32).contiguous()
+    keep = torch.zeros(B, K, dtype=I32, device=boxes.device)
+    kc = torch.zeros(B, dtype=I32, device=boxes.device)
+    check(lib().fdet_nms(ptr(boxes), ptr(scores), ptr(counts, I32), B, K, float(iou_threshold), ptr(keep, I32),
+                         ptr(kc, I32), stream()), "fdet_nms")
+    return keep, kc
+
+
+def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """Drop-in for torchvision.ops.nms (keyword names as the reference passes them,
+    datasets/utils.py:164): (K,4) xyxy, (K,) -> int64 kept indices by descending score."""
+    K = boxes.shape[0]
+    if K == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    if K > 4096:
+        raise N.FdetError(f"nms: K={K} > 4096 candidates per image is not supported by fdet_nms")
+    cnt = torch.tensor([K], dtype=I32, device=boxes.device)
+    keep, kc = nms_batched(boxes.reshape(1, K, 4), scores.reshape(1, K), cnt, iou_threshold)
+    return keep[0, : int(kc[0])].to(torch.int64)
+
+
+def reduce_bounding_boxes(maps: torch.Tensor, prob_threshold: float, iou_threshold: float, img_w: float,
+                          img_h: float):
+    """Batched ReduceBoundingBoxes.forward: (B,5,S,S) -> (out (B,S*S,5), counts (B,))."""
+    maps = _f32(maps)
+    B, C, S, S2 = maps.shape
+    if C != 5 or S != S2:
+        raise ValueError(f"reduce_bounding_boxes: expected (B,5,S,S), got {tuple(maps.shape)}")
+    out = torch.zeros(B, S * S, 5, dtype=F32, device=maps.device)
+    counts = torch.zeros(B, dtype=I32, device=maps.device)
+    check(lib().fdet_reduce_bounding_boxes(ptr(maps), B, S, float(prob_threshold), float(iou_threshold),
+                                           float(img_w), float(img_h), ptr(out), ptr(counts, I32), stream()),
+          "fdet_reduce_bounding_boxes")
+    return out, counts
+
+
+def step_metrics(gt: torch.Tensor, gt_counts: torch.Tensor, pred: torch.Tensor, pred_counts: torch.Tensor):
+    B, K, five = gt.shape
+    if five != 5 or pred.shape != gt.shape:
+        raise ValueError("step_metrics: expected gt/pred (B,K,5)")
+    per = torch.empty(B, 3, dtype=F32, device=gt.device)
+    tot = torch.empty(3, dtype=F32, device=gt.device)
+    check(lib().fdet_step_metrics(ptr(_f32(gt)), ptr(gt_counts.to(I32).contiguous(), I32), ptr(_f32(pred)),
+                                  ptr(pred_counts.to(I32).contiguous(), I32), B, K, ptr(per), ptr(tot), stream()),
+          "fdet_step_metrics")
+    return per, tot
+
+
+def u8_to_f32_norm(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype != torch.uint8:
+        raise TypeError("u8_to_f32_norm expects uint8")
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=F32, device=x.device)
+    check(lib().fdet_u8_to_f32_norm(ptr(x, torch.uint8), ptr(out), x.numel(), stream()), "fdet_u8_to_f32_norm")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# optimiser / dropout
+# ------------------------------------------------------------------------------------------
+def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
+              lr: float = 1e-4, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+              grad_scale: float = 1.0) -> None:
+    n = param.numel()
+    if not (grad.numel() == exp_avg.numel() == exp_avg_sq.numel() == n):
+        raise ValueError("adam_step: buffer sizes differ")
+    check(lib().fdet_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), n, int(step), float(lr),
+                               float(beta1), float(beta2), float(eps), float(grad_scale), stream()), "fdet_adam_step")
+
+
+def dropout_scales(out: torch.Tensor, p: float, seed: int, offset: int) -> torch.Tensor:
+    check(lib().fdet_dropout_scales(ptr(out), out.numel(), float(p), int(seed) & (2**64 - 1),
+                                    int(offset) & (2**64 - 1), stream()), "fdet_dropout_scales")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# conv stack primitives (shapes are validated here; the kernels trust them)
+# ------------------------------------------------------------------------------------------
+def _chk4(t: torch.Tensor, shape, name):
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
+def packed_sizes(cout: int, cin: int) -> Tuple[int, int]:
+    cop, cip = (cout + 31) // 32 * 32, (cin + 31) // 32 * 32
+    return cin * 9 * cop, cout * 9 * cip
+
+
+def pack_conv3x3_weights(w: torch.Tensor, wpk_fwd: Optional[torch.Tensor], wpk_bwd: Optional[torch.Tensor]) -> None:
+    cout, cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("pack_conv3x3_weights: 3x3 kernels only")
+    nf, nb = packed_sizes(cout, cin)
+    if wpk_fwd is not None and wpk_fwd.numel() != nf:
+        raise ValueError(f"wpk_fwd must hold {nf} floats")
+    if wpk_bwd is not None and wpk_bwd.numel() != nb:
+        raise ValueError(f"wpk_bwd must hold {nb} floats")
+    check(lib().fdet_pack_conv3x3_weights(ptr(w), cout, cin, ptr(wpk_fwd), ptr(wpk_bwd), stream()),
+          "fdet_pack_conv3x3_weights")
+
+
+def conv3x3_fwd(x, wpk, bias, cout: int, y_full=None, skip=None, drop_scale=None, y_out=None, slope: float = 0.2):
+    Nn, cin, H, W = x.shape
+    if wpk.numel() != packed_sizes(cout, cin)[0]:
+        raise ValueError("conv3x3_fwd: packed weight size does not match (Cout,Cin)")
+    for t, nm in ((y_full, "y_full"), (skip, "skip"), (y_out, "y_out")):
+        if t is not None:
+            _chk4(t, (Nn, cout, H, W), nm)
+    if bias is not None:
+        _chk4(bias, (cout,), "bias")
+    if drop_scale is not None:
+        _chk4(drop_scale, (Nn, cout), "drop_scale")
+    check(lib().fdet_conv3x3_fwd(ptr(x), ptr(wpk), ptr(bias), ptr(y_full), ptr(skip), ptr(drop_scale), ptr(y_out),
+                                 Nn, cin, cout, H, W, 1, float(slope), stream()), "fdet_conv3x3_fwd")
+
+
+def conv3x3_dgrad(dz, wpk_bwd, cin: int, dx, act=None, add=None, slope: float = 0.2):
+    Nn, cout, H, W = dz.shape
+    if wpk_bwd.numel() != packed_sizes(cout, cin)[1]:
+        raise ValueError("conv3x3_dgrad: packed weight size does not match (Cout,Cin)")
+    _chk4(dx, (Nn, cin, H, W), "dx")
+    for t, nm in ((act, "act"), (add, "add")):
+        if t is not None:
+            _chk4(t, (Nn, cin, H, W), nm)
+    check(lib().fdet_conv3x3_dgrad(ptr(dz), ptr(wpk_bwd), ptr(act), ptr(add), ptr(dx), Nn, cin, cout, H, W,
+                                   float(slope), stream()), "fdet_conv3x3_dgrad")
+
+
+def conv3x3_wgrad_ws_bytes(Nn, cin, cout, H, W) -> int:
+    return int(lib().fdet_conv3x3_wgrad_ws_bytes(Nn, cin, cout, H, W))
+
+
+def conv3x3_wgrad(x, dz, dW, db, ws):
+    Nn, cin, H, W = x.shape
+    cout = dz.shape[1]
+    _chk4(dz, (Nn, cout, H, W), "dz")
+    _chk4(dW, (cout, cin, 3, 3), "dW")
+    _chk4(db, (cout,), "db")
+    check(lib().fdet_conv3x3_wgrad(ptr(x), ptr(dz), ptr(dW), ptr(db), ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
+                                   Nn, cin, cout, H, W, stream()), "fdet_conv3x3_wgrad")
+
+
+def block_tail_fwd(c, x, drop_scale, out, pool: int):
+    Nn, F_, H, W = c.shape
+    _chk4(x, c.shape, "x")
+    _chk4(out, (Nn, F_, H // pool, W // pool), "out")
+    if drop_scale is not None:
+        _chk4(drop_scale, (Nn, F_), "drop_scale")
+    check(lib().fdet_block_tail_fwd(ptr(c), ptr(x), ptr(drop_scale), ptr(out), Nn, F_, H, W, pool, stream()),
+          "fdet_block_tail_fwd")
+
+
+def block_tail_bwd(dout, c, x, drop_scale, dz2, de, pool: int, slope: float = 0.2):
+    Nn, F_, H, W = c.shape
+    _chk4(dout, (Nn, F_, H // pool, W // pool), "dout")
+    _chk4(dz2, c.shape, "dz2")
+    if pool == 2:
+        _chk4(x, c.shape, "x")
+        _chk4(de, c.shape, "de")
+    if drop_scale is not None:
+        _chk4(drop_scale, (Nn, F_), "drop_scale")
+    check(lib().fdet_block_tail_bwd(ptr(dout), ptr(c), ptr(x), ptr(drop_scale), ptr(dz2), ptr(de), Nn, F_, H, W, pool,
+                                    float(slope), stream()), "fdet_block_tail_bwd")
+
+
+def stem_ws_bytes(Nn, cin, F_, H, W, k, stride, pad) -> int:
+    return int(lib().fdet_stem_ws_bytes(Nn, cin, F_, H, W, k, stride, pad))
+
+
+def stem_fwd(x, w, bias, y, ws, k, stride, pad):
+    Nn, cin, H, W = x.shape
+    F_ = w.shape[0]
+    _chk4(w, (F_, cin, k, k), "w")
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    _chk4(y, (Nn, F_, Ho, Wo), "y")
+    check(lib().fdet_stem_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
+                              Nn, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_fwd")
+
+
+def stem_wgrad(x, dy, dW, db, ws, k, stride, pad):
+    Nn, cin, H, W = x.shape
+    F_ = dW.shape[0]
+    _chk4(dW, (F_, cin, k, k), "dW")
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    _chk4(dy, (Nn, F_, Ho, Wo), "dy")
+    check(lib().fdet_stem_wgrad(ptr(x), ptr(dy), ptr(dW), ptr(db), ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
+                                Nn, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_wgrad")
+
+
+def head_fwd(x, drop_scale, w, bias, y, k, pad):
+    Nn, F_, H, W = x.shape
+    _chk4(w, (5, F_, k, k), "w")
+    So, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    _chk4(y, (Nn, 5, So, Wo), "y")
+    if drop_scale is not None:
+        _chk4(drop_scale, (Nn, F_), "drop_scale")
+    check(lib().fdet_head_fwd(ptr(x), ptr(drop_scale), ptr(w), ptr(bias), ptr(y), Nn, F_, H, W, k, pad, stream()),
+          "fdet_head_fwd")
+
+
+def head_bwd_ws_bytes(Nn, F_, H, W, k, pad) -> int:
+    return int(lib().fdet_head_bwd_ws_bytes(Nn, F_, H, W, k, pad))
+
+
+def head_bwd(x, drop_scale, w, y, dy, dx, dW, db, ws, k, pad):
+    Nn, F_, H, W = x.shape
+    _chk4(w, (5, F_, k, k), "w")
+    _chk4(dW, (5, F_, k, k), "dW")
+    _chk4(dx, x.shape, "dx")
+    _chk4(dy, y.shape, "dy")
+    check(lib().fdet_head_bwd(ptr(x), ptr(drop_scale), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dW), ptr(db),
+                              ptr(ws, ws.dtype), ws.numel() * ws.element_size(), Nn, F_, H, W, k, pad, stream()),
+          "fdet_head_bwd")

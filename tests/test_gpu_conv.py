@@ -1,0 +1,138 @@
+"""GPU parity of the conv-stack primitives against a plain PyTorch fp32 CPU reference of the
+same op (floating point: tolerance 1e-4 relative to the tensor's scale, as the north star
+states; fp32 MFMA is an exact fp32 FMA chain, so observed errors are ~1e-6)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    import fdet_amd
+    from fdet_amd import hotpath
+    return hotpath
+
+
+def close(a, b, tol=1e-4):
+    a = a.cpu().double(); b = b.cpu().double()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"max err {err} vs scale {scale}"
+
+
+SHAPES = [(3, 64, 60, 60), (5, 64, 15, 15), (4, 64, 30, 30), (2, 32, 30, 30), (2, 8, 7, 9), (1, 16, 20, 20),
+          (2, 128, 15, 15), (33, 64, 15, 15)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv3x3_fwd_dgrad_wgrad(hp, shape):
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(N * 1000 + C + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    skip = torch.randn(N, C, H, W, generator=g)
+    scale = (torch.rand(N, C, generator=g) > 0.25).float() / 0.75
+    nf, nb = hp.packed_sizes(C, C)
+    wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda")
+    hp.pack_conv3x3_weights(w.cuda(), wf, wb)
+    xd = x.cuda()
+    # forward, conv1 flavour and conv2 flavour
+    y_full = torch.full((N, C, H, W), float("nan"), device="cuda")
+    y_out = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.conv3x3_fwd(xd, wf, b.cuda(), C, y_full=y_full, skip=skip.cuda(), drop_scale=scale.cuda(), y_out=y_out)
+    z = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
+    close(y_full, z)
+    close(y_out, z * scale[:, :, None, None] + skip)
+    # data gradient with fused lrelu' and add
+    dz = torch.randn(N, C, H, W, generator=g)
+    act = torch.randn(N, C, H, W, generator=g)
+    add = torch.randn(N, C, H, W, generator=g)
+    dx = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.conv3x3_dgrad(dz.cuda(), wb, C, dx, act=act.cuda(), add=add.cuda())
+    ref = F.conv_transpose2d(dz, w, padding=1) * torch.where(act > 0, 1.0, 0.2) + add
+    close(dx, ref)
+    # weight gradient
+    ws = torch.empty(hp.conv3x3_wgrad_ws_bytes(N, C, C, H, W) // 4, device="cuda")
+    dW = torch.full((C, C, 3, 3), float("nan"), device="cuda"); db = torch.full((C,), float("nan"), device="cuda")
+    hp.conv3x3_wgrad(xd, dz.cuda(), dW, db, ws)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    F.conv2d(xr, wr, br, padding=1).backward(dz)
+    close(dW, wr.grad)
+    close(db, br.grad)
+
+
+@pytest.mark.parametrize("pool", [1, 2])
+def test_block_tail(hp, pool):
+    g = torch.Generator().manual_seed(pool)
+    N, C, H, W = 3, 16, 12, 20
+    c = torch.randn(N, C, H, W, generator=g)
+    x = torch.randn(N, C, H, W, generator=g)
+    x[0, 0, :2, :2] = 1.0; c[0, 0, :2, :2] = 0.0           # a tie inside one window: first max wins
+    scale = (torch.rand(N, C, generator=g) > 0.25).float() / 0.75
+    out = torch.empty(N, C, H // pool, W // pool, device="cuda")
+    hp.block_tail_fwd(c.cuda(), x.cuda(), scale.cuda(), out, pool)
+    cr = c.clone().requires_grad_(True); xr = x.clone().requires_grad_(True)
+    e = F.leaky_relu(cr, 1.0) * scale[:, :, None, None] + xr
+    ref = F.max_pool2d(e, 2) if pool == 2 else e
+    assert torch.equal(out.cpu(), ref.detach())
+    dout = torch.randn(ref.shape, generator=g)
+    # reference for dz2 = d/dz2 where c = lrelu(z2): chain through lrelu'(c)
+    z2 = torch.where(c > 0, c, c / 0.2).requires_grad_(True)
+    e2 = F.leaky_relu(z2, 0.2) * scale[:, :, None, None] + xr
+    r2 = F.max_pool2d(e2, 2) if pool == 2 else e2
+    gz, gx = torch.autograd.grad(r2, [z2, xr], dout)
+    dz2 = torch.empty(N, C, H, W, device="cuda"); de = torch.empty(N, C, H, W, device="cuda")
+    hp.block_tail_bwd(dout.cuda(), c.cuda(), x.cuda(), scale.cuda(), dz2, de if pool == 2 else None, pool)
+    assert torch.allclose(dz2.cpu(), gz, rtol=1e-6, atol=1e-6)
+    if pool == 2:
+        assert torch.equal(de.cpu(), gx)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 480, 10, 8, 2), (3, 8, 480, 10, 8, 2), (2, 32, 240, 3, 2, 1),
+                                 (1, 64, 640, 3, 2, 1)])
+def test_stem(hp, cfg):
+    N, Fo, size, k, s, p = cfg
+    g = torch.Generator().manual_seed(Fo + size)
+    x = torch.rand(N, 3, size, size, generator=g)
+    w = torch.randn(Fo, 3, k, k, generator=g) * 0.1
+    b = torch.randn(Fo, generator=g)
+    Ho = (size + 2 * p - k) // s + 1
+    ws = torch.empty(hp.stem_ws_bytes(N, 3, Fo, size, size, k, s, p) // 4, device="cuda")
+    y = torch.full((N, Fo, Ho, Ho), float("nan"), device="cuda")
+    hp.stem_fwd(x.cuda(), w.cuda(), b.cuda(), y, ws, k, s, p)
+    close(y, F.conv2d(x, w, b, stride=s, padding=p))
+    dy = torch.randn(N, Fo, Ho, Ho, generator=g)
+    wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    F.conv2d(x, wr, br, stride=s, padding=p).backward(dy)
+    dW = torch.full((Fo, 3, k, k), float("nan"), device="cuda"); db = torch.full((Fo,), float("nan"), device="cuda")
+    hp.stem_wgrad(x.cuda(), dy.cuda(), dW, db, ws, k, s, p)
+    close(dW, wr.grad)
+    close(db, br.grad)
+
+
+@pytest.mark.parametrize("cfg", [(3, 64, 15, 6, 0), (2, 8, 15, 6, 0), (2, 32, 15, 3, 1), (2, 64, 20, 3, 1), (1, 128, 15, 6, 0)])
+def test_head(hp, cfg):
+    N, Fi, H, k, p = cfg
+    g = torch.Generator().manual_seed(Fi + H + k)
+    x = torch.randn(N, Fi, H, H, generator=g)
+    w = torch.randn(5, Fi, k, k, generator=g) * 0.05
+    b = torch.randn(5, generator=g)
+    scale = (torch.rand(N, Fi, generator=g) > 0.5).float() / 0.5
+    S = H + 2 * p - k + 1
+    y = torch.full((N, 5, S, S), float("nan"), device="cuda")
+    hp.head_fwd(x.cuda(), scale.cuda(), w.cuda(), b.cuda(), y, k, p)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    ref = torch.sigmoid(F.conv2d(xr * scale[:, :, None, None], wr, br, padding=p))
+    close(y, ref.detach(), 1e-5)
+    dy = torch.randn(N, 5, S, S, generator=g)
+    ref.backward(dy)
+    ws = torch.empty(hp.head_bwd_ws_bytes(N, Fi, H, H, k, p) // 4, device="cuda")
+    dx = torch.full((N, Fi, H, H), float("nan"), device="cuda")
+    dW = torch.full((5, Fi, k, k), float("nan"), device="cuda"); db = torch.full((5,), float("nan"), device="cuda")
+    hp.head_bwd(x.cuda(), scale.cuda(), w.cuda(), y, dy.cuda(), dx, dW, db, ws, k, p)
+    close(dx, xr.grad)
+    close(dW, wr.grad)
+    close(db, br.grad)
