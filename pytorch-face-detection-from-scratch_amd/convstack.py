@@ -1,0 +1,217 @@
+"""Conv-stack engine: the PoolResnet / Resnet forward and hand-written backward as a fixed
+sequence of HIP kernel launches (no autograd graph inside).
+
+Reference: models/PoolResnet.py:11-105, models/Resnet.py:10-99 (forward); the backward is the
+autograd of that forward, restated kernel by kernel:
+
+    stem -> [ conv1+lrelu -> conv2+lrelu -> dropout2d*skip-add (-> maxpool) ] x blocks
+         -> dropout2d(0.5) -> head conv -> sigmoid
+
+Activations saved for backward per block: a (conv1 output), c (conv2 output, pre-dropout) and
+the block input; everything else is recomputed in the fused tails.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import hotpath as hp
+
+F32 = torch.float32
+
+
+@dataclass
+class StackGeometry:
+    kind: str
+    filters: int
+    in_ch: int
+    H: int
+    W: int
+    S: int
+    num_blocks: int
+    stem_k: int
+    stem_s: int
+    stem_p: int
+    head_k: int
+    head_p: int
+    pool_mult: int          # pool iff H > pool_mult*S  (PoolResnet.py:41: 2, Resnet.py:38: 1)
+
+    def levels(self):
+        """[(H_in, pool)] per block and the stem output size."""
+        h0 = (self.H + 2 * self.stem_p - self.stem_k) // self.stem_s + 1
+        w0 = (self.W + 2 * self.stem_p - self.stem_k) // self.stem_s + 1
+        if h0 != w0:
+            raise ValueError("square inputs only (reference swaps width/height, datasets/utils.py:107)")
+        out, h = [], h0
+        for _ in range(self.num_blocks):
+            pool = 2 if h > self.pool_mult * self.S else 1
+            if pool == 2 and h % 2:
+                raise ValueError(f"cannot 2x2-pool an odd {h}x{h} map")
+            out.append((h, pool))
+            h //= pool
+        s_out = h + 2 * self.head_p - self.head_k + 1
+        if s_out != self.S:
+            # the reference only fails later, in yolo_loss, with a shape mismatch
+            raise ValueError(f"input {self.H}x{self.W} with this stem/head reaches a {s_out}x{s_out} grid, "
+                             f"not num_of_patches={self.S}")
+        return h0, out
+
+
+PARAM_ORDER_DOC = "conv1.{weight,bias}, residual_blocks.k.conv{1,2}.{weight,bias}, out.{weight,bias}"
+
+
+class ConvStack:
+    """Owns packed weights, workspaces and saved activations; parameters are passed in as a
+    dict of GPU tensors named like the reference's state_dict."""
+
+    def __init__(self, geo: StackGeometry):
+        self.geo = geo
+        self.h0, self.lv = geo.levels()
+        self._packed_key = None
+        self._wpk: Dict[str, torch.Tensor] = {}
+        self._ws: Dict[str, torch.Tensor] = {}
+        self.slope = 0.2
+
+    # ------------------------------------------------------------------ weights
+    def _ensure_packed(self, P: Dict[str, torch.Tensor], force: bool = False):
+        key = tuple((P[k].data_ptr(), P[k]._version) for k in sorted(P) if k.endswith("weight"))
+        if not force and key == self._packed_key:
+            return
+        F_ = self.geo.filters
+        nf, nb = hp.packed_sizes(F_, F_)
+        dev = P["conv1.weight"].device
+        for k in range(self.geo.num_blocks):
+            for j in (1, 2):
+                name = f"residual_blocks.{k}.conv{j}"
+                if name + ".f" not in self._wpk:
+                    self._wpk[name + ".f"] = torch.empty(nf, dtype=F32, device=dev)
+                    self._wpk[name + ".b"] = torch.empty(nb, dtype=F32, device=dev)
+                hp.pack_conv3x3_weights(P[name + ".weight"], self._wpk[name + ".f"], self._wpk[name + ".b"])
+        self._packed_key = key
+
+    def mark_params_dirty(self):
+        """Call after the parameters were updated behind torch's back (fdet_adam_step)."""
+        self._packed_key = None
+
+    def _workspace(self, name: str, nbytes: int, dev) -> torch.Tensor:
+        n = (nbytes + 3) // 4
+        t = self._ws.get(name)
+        if t is None or t.numel() < n or t.device != dev:
+            t = torch.empty(max(n, 4), dtype=F32, device=dev)
+            self._ws[name] = t
+        return t
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], masks: Optional[Dict[str, torch.Tensor]] = None,
+                save: bool = False):
+        """x (N,C,H,W) f32 on the GPU -> y (N,5,S,S).  masks: per-(n,c) dropout scales
+        {"residual_blocks.k": (N,F), "head": (N,F)} or None (eval).  save=True keeps what
+        backward needs and returns it as the second value."""
+        g = self.geo
+        if x.dim() != 4 or tuple(x.shape[1:]) != (g.in_ch, g.H, g.W):
+            raise ValueError(f"expected input (N,{g.in_ch},{g.H},{g.W}), got {tuple(x.shape)}")
+        if x.dtype != F32 or not x.is_contiguous():
+            x = x.to(F32).contiguous()
+        self._ensure_packed(P)
+        N, F_, dev = x.shape[0], g.filters, x.device
+        ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
+        h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev)
+        hp.stem_fwd(x, P["conv1.weight"], P["conv1.bias"], h, ws, g.stem_k, g.stem_s, g.stem_p)
+        saved = {"x": x, "blocks": [], "masks": masks} if save else None
+        for k, (hk, pool) in enumerate(self.lv):
+            name = f"residual_blocks.{k}"
+            sc = masks[name] if masks is not None else None
+            a = torch.empty(N, F_, hk, hk, dtype=F32, device=dev)
+            hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], F_, y_full=a, slope=self.slope)
+            out = torch.empty(N, F_, hk // pool, hk // pool, dtype=F32, device=dev)
+            if pool == 2:
+                c = torch.empty_like(a)
+                hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, slope=self.slope)
+                hp.block_tail_fwd(c, h, sc, out, 2)
+            else:
+                c = torch.empty_like(a) if save else None
+                hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, skip=h,
+                               drop_scale=sc, y_out=out, slope=self.slope)
+            if save:
+                saved["blocks"].append((h, a, c))
+            h = out
+        y = torch.empty(N, 5, g.S, g.S, dtype=F32, device=dev)
+        hp.head_fwd(h, masks["head"] if masks is not None else None, P["out.weight"], P["out.bias"], y, g.head_k, g.head_p)
+        if save:
+            saved["h_last"] = h
+            saved["y"] = y
+        return y, saved
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, saved, dy: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
+                 after_block=None) -> None:
+        """dy = d loss / d y (N,5,S,S).  Writes every parameter gradient into G[name]
+        (overwrites; same names/shapes as P).  `after_block(k)` is called once block k's
+        gradients have been enqueued (data-parallel bucket launch)."""
+        g = self.geo
+        F_ = g.filters
+        x, masks = saved["x"], saved["masks"]
+        N, dev = x.shape[0], x.device
+        h_last, y = saved["h_last"], saved["y"]
+        if tuple(dy.shape) != tuple(y.shape):
+            raise ValueError(f"dy shape {tuple(dy.shape)} != y shape {tuple(y.shape)}")
+        dy = dy.to(F32).contiguous()
+        hl = h_last.shape[2]
+        ws = self._workspace("head", hp.head_bwd_ws_bytes(N, F_, hl, hl, g.head_k, g.head_p), dev)
+        dout = torch.empty_like(h_last)
+        hp.head_bwd(h_last, masks["head"] if masks is not None else None, P["out.weight"], y, dy, dout,
+                    G["out.weight"], G["out.bias"], ws, g.head_k, g.head_p)
+        for k in reversed(range(g.num_blocks)):
+            hk, pool = self.lv[k]
+            name = f"residual_blocks.{k}"
+            xin, a, c = saved["blocks"][k]
+            sc = masks[name] if masks is not None else None
+            dz2 = torch.empty_like(a)
+            de = torch.empty_like(a) if pool == 2 else None
+            hp.block_tail_bwd(dout, c, xin, sc, dz2, de, pool, self.slope)
+            if pool == 1:
+                de = dout
+            wws = self._workspace("wgrad", hp.conv3x3_wgrad_ws_bytes(N, F_, F_, hk, hk), dev)
+            hp.conv3x3_wgrad(a, dz2, G[name + ".conv2.weight"], G[name + ".conv2.bias"], wws)
+            dz1 = torch.empty_like(a)
+            hp.conv3x3_dgrad(dz2, self._wpk[name + ".conv2.b"], F_, dz1, act=a, slope=self.slope)
+            hp.conv3x3_wgrad(xin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], wws)
+            dx = dz2                                   # reuse: dz2 is dead after its wgrad/dgrad
+            hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], F_, dx, add=de, slope=self.slope)
+            dout = dx
+            if after_block is not None:
+                after_block(k)
+        ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
+        hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p)
+
+
+def param_names(num_blocks: int) -> List[str]:
+    """State-dict order of the reference modules (models/PoolResnet.py:70-89)."""
+    names = ["conv1.weight", "conv1.bias"]
+    for k in range(num_blocks):
+        for j in (1, 2):
+            names += [f"residual_blocks.{k}.conv{j}.weight", f"residual_blocks.{k}.conv{j}.bias"]
+    names += ["out.weight", "out.bias"]
+    return names
+
+
+class ConvStackFn(torch.autograd.Function):
+    """Autograd bridge: makes `loss.backward()` work on the model surface (Lightning-style
+    callers).  Forward saves activations inside the engine-owned dict; backward returns one
+    gradient per parameter."""
+
+    @staticmethod
+    def forward(ctx, engine: ConvStack, masks, names, x, *params):
+        P = {n: p.detach() for n, p in zip(names, params)}
+        y, saved = engine.forward(x.detach(), P, masks, save=True)
+        ctx.engine, ctx.saved, ctx.names, ctx.P = engine, saved, names, P
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        G = {n: torch.empty_like(p) for n, p in ctx.P.items()}
+        ctx.engine.backward(ctx.saved, dy, ctx.P, G)
+        ctx.saved = None
+        return (None, None, None, None) + tuple(G[n] for n in ctx.names)

@@ -183,6 +183,7 @@ extern "C" int fdet_conv3x3_wgrad(const float* x, const float* dz, float* dW, fl
   FDET_REQUIRE(x && dz && dW && ws, "conv3x3_wgrad: null pointer");
   FDET_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_wgrad: bad shape");
   const WgPlan p = plan_wgrad(N, Cin, Cout, H, W);
+  FDET_REQUIRE(p.lds <= 160 * 1024, "conv3x3_wgrad: W=%d too wide for the row-band LDS tiling (needs %zu B of LDS)", W, p.lds);
   if (ws_bytes < p.ws_floats * 4)
     return fail(FDET_EWORKSPACE, "conv3x3_wgrad: workspace %zu < %zu bytes", ws_bytes, p.ws_floats * 4);
   WgArgs a;

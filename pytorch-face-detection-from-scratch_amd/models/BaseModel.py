@@ -1,0 +1,111 @@
+"""`BaseModel` with the reference's constructor and methods (models/BaseModel.py:11-71)."""
+import torch
+import torch.nn as nn
+
+from .. import hotpath as hp
+from ..convstack import ConvStack, ConvStackFn, StackGeometry, param_names
+from ..datasets.utils import ReduceBoundingBoxes
+
+
+class BaseModel(nn.Module):
+    def __init__(self, filters, input_shape, num_of_patches, probability_threshold=0.5, iou_threshold=0.5):
+        super().__init__()
+        self.input_shape = input_shape
+        self.num_of_patches = num_of_patches
+        assert (
+            input_shape[1] % num_of_patches == 0 and input_shape[2] % num_of_patches == 0
+        ), f"Input shape {input_shape} cannot be divided into {num_of_patches} patches"
+        self.filters = filters
+        self.probability_threshold = probability_threshold
+        self.iou_threshold = iou_threshold
+        self.reduce_bounding_boxes = ReduceBoundingBoxes(
+            probability_threshold=probability_threshold, iou_threshold=iou_threshold,
+            input_shape=self.input_shape, num_of_patches=self.num_of_patches)
+        self._engine = None
+        self._injected_masks = None
+        self._drop_seed = 0x5EED
+        self._drop_calls = 0
+
+    # -------------------------------------------------------------- conv stack plumbing
+    def _geometry(self) -> StackGeometry:
+        raise NotImplementedError
+
+    @property
+    def engine(self) -> ConvStack:
+        if self._engine is None:
+            self._engine = ConvStack(self._geometry())
+        return self._engine
+
+    def named_stack_params(self):
+        names = param_names(len(self.residual_blocks))
+        sd = dict(self.named_parameters())
+        return names, [sd[n] for n in names]
+
+    def set_dropout_masks(self, masks):
+        """Inject per-(n,c) Dropout2d scale factors (parity tests); None = draw on device."""
+        self._injected_masks = masks
+
+    def _draw_masks(self, n: int, device):
+        if self._injected_masks is not None:
+            return {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in self._injected_masks.items()}
+        nb, F_ = len(self.residual_blocks), self.filters
+        buf = torch.empty(nb + 1, n, F_, dtype=torch.float32, device=device)
+        self._drop_calls += 1
+        base = self._drop_calls * (nb + 1) * n * F_
+        hp.dropout_scales(buf[:nb], 0.25, self._drop_seed, base)                       # ResidualBlock dropout
+        hp.dropout_scales(buf[nb:], 0.5, self._drop_seed, base + nb * n * F_)          # model-level dropout
+        masks = {f"residual_blocks.{k}": buf[k] for k in range(nb)}
+        masks["head"] = buf[nb]
+        return masks
+
+    def _stack_forward(self, x: torch.Tensor) -> torch.Tensor:
+        names, params = self.named_stack_params()
+        if not x.is_cuda:
+            raise hp.N.FdetError("the conv stack runs on the GPU only (no CPU fallback): move model and input to cuda")
+        masks = self._draw_masks(x.shape[0], x.device) if self.training else None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return ConvStackFn.apply(self.engine, masks, names, x, *params)
+        P = {n: p.detach() for n, p in zip(names, params)}
+        return self.engine.forward(x, P, masks, save=False)[0]
+
+    def _preprocess(self, x: torch.Tensor) -> torch.Tensor:
+        """`self.resize(x) / 255.0` (PoolResnet.py:95) for uint8 input at the model resolution
+        (the Resize is then an identity round trip)."""
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        if tuple(x.shape[-2:]) != tuple(self.input_shape[1:]):
+            raise NotImplementedError("on-device bilinear Resize is not built yet: feed images at the model "
+                                      f"resolution {tuple(self.input_shape[1:])}")
+        if x.dtype == torch.uint8:
+            return hp.u8_to_f32_norm(x)
+        return x.float() / 255.0
+
+    # -------------------------------------------------------------- reference surface
+    def summary(self):
+        if self.input_shape is None:
+            raise Exception("Please set 'input_shape'")
+        n = sum(p.numel() for p in self.parameters())
+        print(f"{type(self).__name__}: {n:,} parameters, input {tuple(self.input_shape)}, "
+              f"grid {self.num_of_patches}x{self.num_of_patches}")
+
+    def non_max_suppression(self, x):
+        if len(x.shape) == 4:
+            rows, counts = self.reduce_bounding_boxes.forward_batch(x)
+            counts = counts.tolist()
+            return tuple(rows[i, : counts[i]] if counts[i] else torch.empty(0).reshape(0, 5)
+                         for i in range(x.shape[0]))
+        return self.reduce_bounding_boxes(x)
+
+    def single_non_max_suppression(self, x):
+        return self.reduce_bounding_boxes(x)
+
+    @torch.no_grad()
+    def predict(self, x, probability_threshold=0.5, iou_threshold=0.5):
+        self.reduce_bounding_boxes = ReduceBoundingBoxes(
+            probability_threshold=probability_threshold, iou_threshold=iou_threshold,
+            input_shape=self.input_shape, num_of_patches=self.num_of_patches)
+        x = self._preprocess(x)
+        image = x
+        x = self(x)
+        bbxs = self.non_max_suppression(x)
+        return image, bbxs[0]

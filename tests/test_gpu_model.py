@@ -1,0 +1,164 @@
+"""End-to-end GPU parity of the model surface (PoolResnet / Resnet / ModelMeta) against the
+golden fixtures produced by the reference and against the oracle.
+Tolerances: fp32 outputs / loss within 1e-4 (north star); decoded boxes and keep-sets exact."""
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fd():
+    import fdet_amd
+    return fdet_amd
+
+
+def _load(model, P):
+    model.load_state_dict({k: v.clone() for k, v in P.items()})
+    return model.cuda()
+
+
+def _build(fd, kind, F, size, S, nb):
+    from fdet_amd.models.PoolResnet import PoolResnet
+    from fdet_amd.models.Resnet import Resnet
+    cls = PoolResnet if kind == "poolresnet" else Resnet
+    return cls(filters=F, input_shape=(3, size, size), num_of_patches=S, num_of_residual_blocks=nb)
+
+
+def rel_close(a, b, tol=1e-4):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    scale = max(1e-30, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * max(scale, 1e-3), f"max err {err:.3e}, scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("name,kind,size,S,nb", [("g5_poolresnet_F8", "poolresnet", 480, 10, 10),
+                                                 ("g5_resnet_F8", "resnet", 240, 15, 6)])
+def test_golden_train_step_autograd_path(fd, golden, name, kind, size, S, nb):
+    """state_dict load -> eval forward -> train forward with the reference's dropout masks ->
+    reference loss -> loss.backward() -> SAMSGD.step(), against the reference's numbers."""
+    from fdet_amd.losses.YoloLoss import yolo_loss
+    from fdet_amd.models import ModelMeta
+    g = golden(name)
+    P = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    masks = {k[len("mask/"):]: v for k, v in g.items() if k.startswith("mask/")}
+    model = _load(_build(fd, kind, 8, size, S, nb), P)
+    x = (g["x_u8"].float() / 255.0).cuda()
+    model.eval()
+    with torch.no_grad():
+        y_eval = model(x)
+    assert torch.allclose(y_eval.cpu(), g["y_eval"], atol=1e-4)
+    mm = ModelMeta(model=model, lr=1e-4)
+    (opt,), _ = mm.configure_optimizers()
+    model.train()
+    model.set_dropout_masks(masks)
+    y_hat = mm(x)
+    assert torch.allclose(y_hat.detach().cpu(), g["y_train"], atol=1e-4)
+    y = g["y"].cuda()
+    loss = 0
+    for i in range(y.shape[0]):                       # the reference's per-image loop (ModelMeta.py:173-176)
+        loss = loss + yolo_loss(y_hat[i], y[i])
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * max(1.0, float(g["loss"]))
+    loss.backward()
+    for n, p in model.named_parameters():
+        rel_close(p.grad, g["grad/" + n])
+    opt.step()
+    for n, p in model.named_parameters():
+        refp = g["param_after/" + n]
+        d = (p.detach().cpu() - refp).abs()
+        assert float(d.max()) <= 2.1e-4, n           # Adam's first step is ~lr*sign(g): sign noise at |g|~0
+        assert float((d > 1e-6).float().mean()) < 0.02, n
+
+
+@pytest.mark.parametrize("kind,F,size,S,nb,B", [("poolresnet", 64, 480, 10, 10, 3), ("poolresnet", 32, 480, 10, 10, 2),
+                                                ("resnet", 16, 240, 15, 6, 2)])
+def test_fused_train_steps_vs_oracle(fd, kind, F, size, S, nb, B):
+    """Three fused steps (forward + loss + backward + Adam, no autograd) against the oracle's
+    train_step on the same inputs and dropout masks."""
+    from fdet_amd.models import ModelMeta
+    spec = (O.poolresnet_spec if kind == "poolresnet" else O.resnet_spec)(F, (3, size, size), S, nb)
+    P = O.init_params(spec, seed=3)
+    model = _load(_build(fd, kind, F, size, S, nb), P)
+    mm = ModelMeta(model=model, lr=1e-4)
+    mm.configure_optimizers()
+    model.train()
+    state = {"exp_avg": {k: torch.zeros_like(v) for k, v in P.items()},
+             "exp_avg_sq": {k: torch.zeros_like(v) for k, v in P.items()}}
+    g = torch.Generator().manual_seed(11)
+    for step in range(1, 4):
+        x = torch.rand(B, 3, size, size, generator=g)
+        boxes = O.synthetic_boxes(B, size, seed=step)
+        y = torch.stack([O.encode_targets(b, (size, size), S) for b in boxes])
+        masks = O.make_dropout_masks(spec, B, seed=100 + step)
+        loss_ref, y_ref, G_ref = O.train_step(spec, P, state, step, x, y, masks)
+        model.set_dropout_masks(masks)
+        lsum, y_hat, _ = mm.fused_train_step(x.cuda(), y.cuda())
+        assert torch.allclose(y_hat.cpu(), y_ref, atol=1e-4)
+        assert abs(float(lsum) - float(loss_ref)) <= 1e-4 * max(1.0, float(loss_ref))
+        sp = mm.opt.space
+        names, _ = model.named_stack_params()
+        for i, n in enumerate(names):
+            rel_close(sp.view(sp.grad, i), G_ref[n], 2e-4)
+    for n, p in model.named_parameters():
+        d = (p.detach().cpu() - P[n]).abs()
+        assert float(d.max()) <= 4.1e-4, n
+        assert float((d > 2e-6).float().mean()) < 0.03, n
+
+
+def test_trained_small_archive_demo_path(fd, golden):
+    """demo_model.py path: uint8 frame stacked twice -> forward(predict=1) -> boxes of image 0,
+    with the shipped small PoolResnet weights (thresholds 0.7 / 0.01)."""
+    from fdet_amd.models.PoolResnet import PoolResnet
+    g = golden("g6_trained_small")
+    P = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    model = PoolResnet(filters=32, input_shape=(3, 480, 480), num_of_patches=10, probability_threshold=0.7,
+                       iou_threshold=0.01)
+    model = _load(model, P).eval()
+    for n in range(g["images"].shape[0]):
+        u8 = g["images"][n].cuda()
+        with torch.no_grad():
+            y = model(torch.stack([u8, u8]).float() / 255.0)
+            det = model(torch.stack([u8, u8]), predict=torch.tensor(1))
+        assert torch.allclose(y[0].cpu(), g["y"][n], atol=1e-4)
+        nd = int(g["ndets"][n])
+        assert det.shape == (nd, 5)
+        if nd:
+            assert torch.allclose(det[:, 0].cpu(), g["dets"][n, :nd, 0], atol=1e-4)
+            assert torch.equal(det[:, 1:].cpu(), g["dets"][n, :nd, 1:])
+
+
+def test_modelmeta_step_outputs_vs_oracle(fd):
+    from fdet_amd.models import ModelMeta
+    from fdet_amd.models.PoolResnet import PoolResnet
+    spec = O.poolresnet_spec(16, (3, 480, 480), 10)
+    P = O.init_params(spec, seed=5)
+    P["out.bias"][0] += 1.0                                  # push confidences up so boxes appear
+    model = _load(PoolResnet(16, (3, 480, 480), 10), P).eval()
+    mm = ModelMeta(model=model)
+    B = 6
+    x = torch.rand(B, 3, 480, 480, generator=torch.Generator().manual_seed(1))
+    boxes = O.synthetic_boxes(B, 480, seed=2)
+    y = torch.stack([O.encode_targets(b, (480, 480), 10) for b in boxes])
+    with torch.no_grad():
+        out = mm.validation_step((x.cuda(), y.cuda(), boxes), 0)
+        y_ref = O.model_forward(spec, P, x, None)
+    loss_ref = O.batch_loss(y_ref, y)
+    assert abs(float(out["loss"]) - float(loss_ref)) <= 1e-4 * float(loss_ref)
+    iou, rec, prec = O.step_metrics(y_ref, y, O.ReduceBoundingBoxes(0.5, 0.5, (3, 480, 480), 10))
+    assert abs(float(out["total_iou"]) - iou) <= 1e-4 * max(1.0, abs(iou))
+    assert abs(float(out["total_recall"]) - rec) <= 1e-6
+    assert abs(float(out["total_precision"]) - prec) <= 1e-6
+    # non_max_suppression on a batch returns a tuple of per-image results (BaseModel.py:47-51)
+    res = model.non_max_suppression(y.cuda())
+    assert isinstance(res, tuple) and len(res) == B
+    for n in range(B):
+        ref = O.ReduceBoundingBoxes(0.5, 0.5, (3, 480, 480), 10)(y[n])
+        assert torch.equal(res[n].cpu(), ref)
+
+
+def test_basemodel_asserts_divisibility(fd):
+    from fdet_amd.models.PoolResnet import PoolResnet
+    with pytest.raises(AssertionError):
+        PoolResnet(8, (3, 481, 481), 10)
