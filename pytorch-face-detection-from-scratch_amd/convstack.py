@@ -62,6 +62,50 @@ class StackGeometry:
 PARAM_ORDER_DOC = "conv1.{weight,bias}, residual_blocks.k.conv{1,2}.{weight,bias}, out.{weight,bias}"
 
 
+class KernelTimer:
+    """HIP-event timing of kernel classes on the stream they are launched on (torch's current
+    stream).  Events are only recorded while a timer is attached to the engine; nothing
+    synchronises until summary()."""
+
+    def __init__(self):
+        self.rec = {}          # name -> [list of (start, end)], flops/launch, bytes/launch
+
+    def span(self, name, flops=0.0, nbytes=0.0):
+        return _Span(self, name, flops, nbytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, (evs, flops, nbytes) in self.rec.items():
+            out[name] = (len(evs), sum(a.elapsed_time(b) for a, b in evs), flops, nbytes)
+        return out
+
+
+class _Span:
+    def __init__(self, timer, name, flops, nbytes):
+        self.t, self.name, self.flops, self.nbytes = timer, name, flops, nbytes
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.t.rec.setdefault(self.name, [[], self.flops, self.nbytes])[0].append((self.a, self.b))
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOSPAN = _NoSpan()
+
+
 class ConvStack:
     """Owns packed weights, workspaces and saved activations; parameters are passed in as a
     dict of GPU tensors named like the reference's state_dict."""
@@ -73,6 +117,16 @@ class ConvStack:
         self._wpk: Dict[str, torch.Tensor] = {}
         self._ws: Dict[str, torch.Tensor] = {}
         self.slope = 0.2
+        self.timer: Optional[KernelTimer] = None
+
+    def _t(self, kind: str, N: int, h: int, flops: float = 0.0, nbytes: float = 0.0):
+        if self.timer is None:
+            return _NOSPAN
+        return self.timer.span(f"{kind}@{h}x{h}", flops, nbytes)
+
+    def _conv_flops(self, N: int, h: int) -> float:
+        F_ = self.geo.filters
+        return 2.0 * N * F_ * F_ * 9 * h * h
 
     # ------------------------------------------------------------------ weights
     def _ensure_packed(self, P: Dict[str, torch.Tensor], force: bool = False):
@@ -118,27 +172,34 @@ class ConvStack:
         N, F_, dev = x.shape[0], g.filters, x.device
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
         h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev)
-        hp.stem_fwd(x, P["conv1.weight"], P["conv1.bias"], h, ws, g.stem_k, g.stem_s, g.stem_p)
+        stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
+        with self._t("stem_fwd", N, self.h0, stem_flops):
+            hp.stem_fwd(x, P["conv1.weight"], P["conv1.bias"], h, ws, g.stem_k, g.stem_s, g.stem_p)
         saved = {"x": x, "blocks": [], "masks": masks} if save else None
         for k, (hk, pool) in enumerate(self.lv):
             name = f"residual_blocks.{k}"
             sc = masks[name] if masks is not None else None
             a = torch.empty(N, F_, hk, hk, dtype=F32, device=dev)
-            hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], F_, y_full=a, slope=self.slope)
+            with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk)):
+                hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], F_, y_full=a, slope=self.slope)
             out = torch.empty(N, F_, hk // pool, hk // pool, dtype=F32, device=dev)
             if pool == 2:
                 c = torch.empty_like(a)
-                hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, slope=self.slope)
-                hp.block_tail_fwd(c, h, sc, out, 2)
+                with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk)):
+                    hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, slope=self.slope)
+                with self._t("tail_fwd", N, hk):
+                    hp.block_tail_fwd(c, h, sc, out, 2)
             else:
                 c = torch.empty_like(a) if save else None
-                hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, skip=h,
-                               drop_scale=sc, y_out=out, slope=self.slope)
+                with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk)):
+                    hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, skip=h,
+                                   drop_scale=sc, y_out=out, slope=self.slope)
             if save:
                 saved["blocks"].append((h, a, c))
             h = out
         y = torch.empty(N, 5, g.S, g.S, dtype=F32, device=dev)
-        hp.head_fwd(h, masks["head"] if masks is not None else None, P["out.weight"], P["out.bias"], y, g.head_k, g.head_p)
+        with self._t("head_fwd", N, h.shape[2]):
+            hp.head_fwd(h, masks["head"] if masks is not None else None, P["out.weight"], P["out.bias"], y, g.head_k, g.head_p)
         if save:
             saved["h_last"] = h
             saved["y"] = y
@@ -161,8 +222,9 @@ class ConvStack:
         hl = h_last.shape[2]
         ws = self._workspace("head", hp.head_bwd_ws_bytes(N, F_, hl, hl, g.head_k, g.head_p), dev)
         dout = torch.empty_like(h_last)
-        hp.head_bwd(h_last, masks["head"] if masks is not None else None, P["out.weight"], y, dy, dout,
-                    G["out.weight"], G["out.bias"], ws, g.head_k, g.head_p)
+        with self._t("head_bwd", N, hl):
+            hp.head_bwd(h_last, masks["head"] if masks is not None else None, P["out.weight"], y, dy, dout,
+                        G["out.weight"], G["out.bias"], ws, g.head_k, g.head_p)
         for k in reversed(range(g.num_blocks)):
             hk, pool = self.lv[k]
             name = f"residual_blocks.{k}"
@@ -170,21 +232,29 @@ class ConvStack:
             sc = masks[name] if masks is not None else None
             dz2 = torch.empty_like(a)
             de = torch.empty_like(a) if pool == 2 else None
-            hp.block_tail_bwd(dout, c, xin, sc, dz2, de, pool, self.slope)
+            with self._t("tail_bwd", N, hk):
+                hp.block_tail_bwd(dout, c, xin, sc, dz2, de, pool, self.slope)
             if pool == 1:
                 de = dout
+            fl = self._conv_flops(N, hk)
             wws = self._workspace("wgrad", hp.conv3x3_wgrad_ws_bytes(N, F_, F_, hk, hk), dev)
-            hp.conv3x3_wgrad(a, dz2, G[name + ".conv2.weight"], G[name + ".conv2.bias"], wws)
+            with self._t("conv3x3_wgrad", N, hk, fl):
+                hp.conv3x3_wgrad(a, dz2, G[name + ".conv2.weight"], G[name + ".conv2.bias"], wws)
             dz1 = torch.empty_like(a)
-            hp.conv3x3_dgrad(dz2, self._wpk[name + ".conv2.b"], F_, dz1, act=a, slope=self.slope)
-            hp.conv3x3_wgrad(xin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], wws)
+            with self._t("conv3x3_dgrad", N, hk, fl):
+                hp.conv3x3_dgrad(dz2, self._wpk[name + ".conv2.b"], F_, dz1, act=a, slope=self.slope)
+            with self._t("conv3x3_wgrad", N, hk, fl):
+                hp.conv3x3_wgrad(xin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], wws)
             dx = dz2                                   # reuse: dz2 is dead after its wgrad/dgrad
-            hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], F_, dx, add=de, slope=self.slope)
+            with self._t("conv3x3_dgrad", N, hk, fl):
+                hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], F_, dx, add=de, slope=self.slope)
             dout = dx
             if after_block is not None:
                 after_block(k)
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
-        hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p)
+        stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
+        with self._t("stem_wgrad", N, self.h0, stem_flops):
+            hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p)
 
 
 def param_names(num_blocks: int) -> List[str]:
