@@ -10,11 +10,17 @@
 // zero rows) are computed and dropped; cost (W+1)/W * (H+1)/H.
 //
 // GEMM mapping (forward):  D[co][q] += A[co][k] * B[k][q],  k = (ci, tap)
-//   A = packed weights  wpk[k][co]     (staged per 8-channel chunk into LDS)
-//   B = input band      x[ci][q+off]   (band of R virtual rows + halo rows in LDS)
+//   A = packed weights  wpk[k][co]     (8-channel chunks, LDS)
+//   B = input band      x[ci][q+off]   (band of R virtual rows + halo rows, LDS)
 // MFMA 32x32x2: lanes 0-31 carry k even (channel 2c), lanes 32-63 k odd (channel 2c+1).
 // The data-gradient conv is the same kernel on dz with flipped/transposed packed weights.
+//
+// Workgroup = 4 waves (one per SIMD), each wave owns MT x NT 32x32 tiles; LDS is double
+// buffered and the next chunk is prefetched global->registers while the current chunk's
+// MFMAs run (one barrier per chunk).  Two workgroups share a CU so that one's prologue /
+// epilogue (not MFMA work) overlaps the other's MFMA loop.
 #include "fdet_common.h"
+#include <cstdlib>
 
 using namespace fdet;
 
@@ -22,7 +28,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int CK = 8;   // input channels per LDS chunk
+constexpr int CK = 8;        // input channels per LDS chunk
+constexpr int NTHR = 256;    // 4 waves
+// B prefetch slots per thread (vector items of VW floats)
+__host__ __device__ constexpr int nbmax(int vw) { return vw == 4 ? 6 : (vw == 2 ? 8 : 10); }
 
 struct ConvArgs {
   const float* x;        // [N,Cin,H,W]
@@ -34,28 +43,102 @@ struct ConvArgs {
   float* y_out;          // fwd: z*scale + skip or null
   const float* act;      // dgrad: lrelu' source or null
   int N, Cin, Cout, CoP, H, W, WP, R, VR, CS, nbands, dgrad;
+  int dbg;               // development ablation flags (FDET_CONV_DBG), 0 in production
+  int lpr_log2;          // log2(lanes per staged row), lanes >= W/VW
+  unsigned magic_h1;     // ceil(2^32/(H+1))
+  unsigned magic_rows;   // ceil(2^32/(R+2))
   float slope;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// native vector types (HIP's float4 struct defeats scalar replacement of the prefetch arrays)
 template <int VW> struct Vec;
 template <> struct Vec<1> { using T = float; };
-template <> struct Vec<2> { using T = float2; };
-template <> struct Vec<4> { using T = float4; };
+template <> struct Vec<2> { using T = f32x2; };
+template <> struct Vec<4> { using T = f32x4; };
+template <int VW> __device__ __forceinline__ float vget(const typename Vec<VW>::T& v, int k) { return v[k]; }
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+
+// floor(v/d) for 0 <= v < 2^20, d < 2^12 with magic = ceil(2^32/d); magic == 0 encodes d == 1
+__device__ __forceinline__ int fdiv(int v, unsigned magic) { return magic ? (int)__umulhi((unsigned)v, magic) : v; }
 
 template <int MT, int NT, int VW>
-__global__ void __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
+__global__ void __launch_bounds__(NTHR, 2)
 k_conv3x3(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MB = MT * 32;                 // output channels per block
-  float* A_lds = reinterpret_cast<float*>(smem);                 // [CK*9][MB]
-  float* B_lds = A_lds + CK * 9 * MB;                            // [CK][CS]
+  constexpr int A_ITEMS = CK * 9 * (MB / 4);  // float4 items of one A chunk
+  constexpr int NA = (A_ITEMS + NTHR - 1) / NTHR;
+  constexpr int NBMAX = nbmax(VW);
+  using VT = typename Vec<VW>::T;
+  const int CS = a.CS, WP = a.WP;
+  const int bufsz = CK * 9 * MB + CK * CS;    // floats per buffer (A then B)
+  float* lds = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int band = blockIdx.x, mb = blockIdx.y;
   const int v0 = band * a.R;
-  const int H1 = a.H + 1, WP = a.WP, CS = a.CS;
+  const int H1 = a.H + 1;
 
-  for (int t = tid; t < CK * CS; t += 256) B_lds[t] = 0.f;       // halos stay zero for all chunks
+  // B halos stay zero for all chunks (staging never touches them)
+  for (int t = tid; t < 2 * bufsz; t += NTHR) lds[t] = 0.f;
+
+  // ---- per-thread staging geometry (chunk invariant)
+  const int rows = a.R + 2;
+  const int wv = a.W / VW;
+  const int lpr = 1 << a.lpr_log2;
+  const int xv = tid & (lpr - 1);
+  const int pair0 = tid >> a.lpr_log2, pair_step = NTHR >> a.lpr_log2;
+  const int npairs = CK * rows;
+  int b_src[NBMAX], b_dst[NBMAX];             // src: offset inside a channel-chunk of x; dst: inside B tile; -1 = skip
+#pragma unroll
+  for (int s = 0; s < NBMAX; ++s) {
+    const int pr = pair0 + s * pair_step;
+    b_src[s] = -1; b_dst[s] = 0;
+    if (pr < npairs && xv < wv) {
+      const int ci = fdiv(pr, a.magic_rows), tr = pr - ci * rows;
+      const int v = v0 - 1 + tr;
+      if (v >= 0 && v < a.VR) {
+        const int n = fdiv(v, a.magic_h1), yy = v - n * H1 - 1;
+        if (yy >= 0) {
+          b_src[s] = ((n * a.Cin + ci) * a.H + yy) * a.W + xv * VW;
+          b_dst[s] = ci * CS + tr * WP + 1 + xv * VW;
+        }
+      }
+    }
+  }
+  const size_t chunk_stride = (size_t)CK * a.H * a.W;
+  const float* asrc0 = a.wpk + mb * MB;
+
+  f32x4 pa[NA];
+  VT pb[NBMAX];
+#define FDET_ISSUE_LOADS(C0)                                                                         \
+  {                                                                                                  \
+    const float* asrc = asrc0 + (size_t)(C0) * 9 * a.CoP;                                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < NA; ++s_) {                                              \
+      const int t_ = min(tid + s_ * NTHR, A_ITEMS - 1);                                              \
+      const int row_ = t_ / (MB / 4), c4_ = t_ - row_ * (MB / 4);                                    \
+      pa[s_] = *reinterpret_cast<const f32x4*>(asrc + (size_t)row_ * a.CoP + c4_ * 4);              \
+    }                                                                                                \
+    const float* xsrc = a.x + (size_t)((C0) / CK) * chunk_stride;                                    \
+    _Pragma("unroll") for (int s_ = 0; s_ < NBMAX; ++s_)                                             \
+      pb[s_] = *reinterpret_cast<const VT*>(xsrc + max(b_src[s_], 0)); /* dummy load when skipped */ \
+  }
+#define FDET_WRITE_LDS(BUF)                                                                          \
+  {                                                                                                  \
+    float* buf_ = (BUF);                                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < NA; ++s_) {                                              \
+      const int t_ = tid + s_ * NTHR;                                                                \
+      if (t_ < A_ITEMS) *reinterpret_cast<f32x4*>(buf_ + t_ * 4) = pa[s_];                           \
+    }                                                                                                \
+    float* B_ = buf_ + CK * 9 * MB;                                                                  \
+    _Pragma("unroll") for (int s_ = 0; s_ < NBMAX; ++s_) {                                           \
+      if (b_src[s_] >= 0) {                                                                          \
+        _Pragma("unroll") for (int k_ = 0; k_ < VW; ++k_) B_[b_dst[s_] + k_] = vget<VW>(pb[s_], k_); \
+      }                                                                                              \
+    }                                                                                                \
+  }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -70,93 +153,120 @@ k_conv3x3(const ConvArgs a) {
   for (int t = 0; t < 9; ++t) tapoff[t] = (t / 3) * WP + (t % 3);
 
   const int qwave = wid * NT * 32;
-  const float* Aw = A_lds + half * 9 * MB + l31;
-  const float* Bw = B_lds + half * CS + qwave + l31;
+  const int a_off = half * 9 * MB + l31;
+  const int b_off = CK * 9 * MB + half * CS + qwave + l31;
 
-  const int rows = a.R + 2;
-  const int wv = a.W / VW;
-  const int b_items = CK * rows * wv;
-  using VT = typename Vec<VW>::T;
+  FDET_ISSUE_LOADS(0)
+  __syncthreads();                       // zero fill complete
+  FDET_WRITE_LDS(lds)
+  __syncthreads();
 
-  for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-    __syncthreads();                                             // previous chunk consumed (and zero fill done)
-    // ---- stage A: rows (c0*9 .. (c0+CK)*9) x MB columns of wpk
-    {
-      const float* src = a.wpk + (size_t)c0 * 9 * a.CoP + mb * MB;
-      for (int t = tid; t < CK * 9 * (MB / 4); t += 256) {
-        const int row = t / (MB / 4), c4 = t - row * (MB / 4);
-        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)row * a.CoP + c4 * 4);
-        *reinterpret_cast<float4*>(A_lds + row * MB + c4 * 4) = v;
+  const int nch = a.Cin / CK;
+  for (int c = 0; c < nch; ++c) {
+    const float* buf = lds + (c & 1) * bufsz;
+    if (c + 1 < nch && !(a.dbg & 2)) FDET_ISSUE_LOADS((c + 1) * CK)
+    const float* Aw = buf + a_off;
+    const float* Bw = buf + b_off;
+    // software-pipelined operand fetch: the LDS reads of k-pair kk+1 are issued before the
+    // MFMAs of k-pair kk (pinned with sched_barrier), so their latency hides under 512+ cycles
+    // of MFMA issue instead of stalling every group.
+    float av[2][MT], bv[2][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) av[0][m] = Aw[m * 32];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bv[0][n] = Bw[tapoff[0] + n * 32];
+#pragma unroll
+    for (int kk = 0; kk < (CK / 2) * 9; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < (CK / 2) * 9) {
+        const int cp = (kk + 1) / 9, t = (kk + 1) % 9;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[nxt][m] = Aw[(cp * 2 * 9 + t) * MB + m * 32];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[nxt][n] = Bw[cp * 2 * CS + tapoff[t] + n * 32];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m], bv[cur][n], acc[m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- stage B: CK channels x (R+2) virtual rows x W columns
-    for (int t = tid; t < b_items; t += 256) {
-      const int ci = t / (rows * wv);
-      const int rem = t - ci * (rows * wv);
-      const int tr = rem / wv, xv = rem - tr * wv;
-      const int v = v0 - 1 + tr;
-      if (v < 0 || v >= a.VR) continue;
-      const int n = v / H1, yy = v - n * H1 - 1;
-      if (yy < 0) continue;
-      const VT val = *reinterpret_cast<const VT*>(
-          a.x + (((size_t)n * a.Cin + c0 + ci) * a.H + yy) * a.W + xv * VW);
-      float* dst = B_lds + ci * CS + tr * WP + 1 + xv * VW;
-      const float* vs = reinterpret_cast<const float*>(&val);
-#pragma unroll
-      for (int k = 0; k < VW; ++k) dst[k] = vs[k];
-    }
-    __syncthreads();
-    // ---- MFMA: CK/2 channel pairs x 9 taps
-#pragma unroll
-    for (int cp = 0; cp < CK / 2; ++cp) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        float av[MT], bv[NT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) av[m] = Aw[(cp * 2 * 9 + t) * MB + m * 32];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) bv[n] = Bw[cp * 2 * CS + tapoff[t] + n * 32];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int n = 0; n < NT; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-      }
-    }
+    if (c + 1 < nch && !(a.dbg & 4)) FDET_WRITE_LDS(lds + ((c + 1) & 1) * bufsz)
+    if (!(a.dbg & 8)) __syncthreads();
   }
 
-  // ---- epilogue
+  // ---- epilogue.  Loads (bias, skip, scale, act) are batched per 32x32 tile ahead of the
+  // stores; the restrict-qualified locals tell the compiler stores cannot feed later loads.
+  const float* __restrict__ g_bias = a.bias;
+  const float* __restrict__ g_skip = a.skip;
+  const float* __restrict__ g_scale = a.scale;
+  const float* __restrict__ g_act = a.act;
+  float* __restrict__ g_full = a.y_full;
+  float* __restrict__ g_out = a.y_out;
   const int qlimit = a.R * WP;
+  const size_t HW = (size_t)a.H * a.W;
+  bool okn[NT];
+  size_t basen[NT];
+  int imgn[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int q = qwave + n * 32 + l31;
     const int tr = q / WP, ox = q - tr * WP;
     const int v = v0 + tr;
     const int img = v / H1, oy = v - img * H1 - 1;
-    const bool ok = (q < qlimit) && (ox < a.W) && (v < a.VR) && (oy >= 0);
-    if (!ok) continue;
+    okn[n] = (q < qlimit) && (ox < a.W) && (v < a.VR) && (oy >= 0) && !((a.dbg & 1) && acc[0][n][0] != 12345.f);
+    basen[n] = ((size_t)img * a.Cout * a.H + oy) * a.W + ox;
+    imgn[n] = img;
+  }
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+  for (int m = 0; m < MT; ++m) {
+    const int cobase = mb * MB + m * 32 + 4 * half;      // + (r&3) + 8*(r>>2)
+    float bz[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = mb * MB + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co >= a.Cout) continue;
-        const size_t idx = (((size_t)img * a.Cout + co) * a.H + oy) * a.W + ox;
-        float z = acc[m][n][r];
-        if (!a.dgrad) {
-          if (a.bias) z += a.bias[co];
+    for (int r = 0; r < 16; ++r) {
+      const int co = cobase + (r & 3) + 8 * (r >> 2);
+      bz[r] = (g_bias && co < a.Cout) ? g_bias[co] : 0.f;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      if (!okn[n]) continue;
+      const size_t idx0 = basen[n] + (size_t)cobase * HW;
+      float t0[16], t1[16];
+      if (!a.dgrad) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          const bool cok = cobase + cr < a.Cout;
+          t0[r] = (g_out && g_skip && cok) ? g_skip[idx0 + cr * HW] : 0.f;
+          t1[r] = (g_out && g_scale && cok) ? g_scale[(size_t)imgn[n] * a.Cout + cobase + cr] : 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          if (cobase + cr >= a.Cout) continue;
+          float z = acc[m][n][r] + bz[r];
           z = z > 0.f ? z : z * a.slope;
-          if (a.y_full) a.y_full[idx] = z;
-          if (a.y_out) {
-            float e = z;
-            if (a.scale) e *= a.scale[(size_t)img * a.Cout + co];
-            if (a.skip) e += a.skip[idx];
-            a.y_out[idx] = e;
-          }
-        } else {
-          if (a.act) z *= (a.act[idx] > 0.f) ? 1.f : a.slope;
-          if (a.skip) z += a.skip[idx];
-          a.y_full[idx] = z;
+          if (g_full) g_full[idx0 + cr * HW] = z;
+          if (g_out) g_out[idx0 + cr * HW] = z * t1[r] + t0[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          const bool cok = cobase + cr < a.Cout;
+          t0[r] = (g_act && cok) ? g_act[idx0 + cr * HW] : 1.f;
+          t1[r] = (g_skip && cok) ? g_skip[idx0 + cr * HW] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          if (cobase + cr >= a.Cout) continue;
+          float z = acc[m][n][r];
+          if (g_act) z *= (t0[r] > 0.f) ? 1.f : a.slope;
+          z += t1[r];
+          g_full[idx0 + cr * HW] = z;
         }
       }
     }
@@ -183,35 +293,65 @@ k_pack3x3(const float* __restrict__ w, int Cout, int Cin, int CoP, int CiP, floa
   }
 }
 
+unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
 template <int MT, int NT>
 int launch_conv_vw(const ConvArgs& a, int vw, size_t lds, dim3 grid, hipStream_t st) {
   auto set = [&](const void* f) {
-    if (lds > 64 * 1024) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   };
-  if (vw == 4) { set((const void*)k_conv3x3<MT, NT, 4>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 4>), grid, dim3(256), lds, st, a); }
-  else if (vw == 2) { set((const void*)k_conv3x3<MT, NT, 2>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 2>), grid, dim3(256), lds, st, a); }
-  else { set((const void*)k_conv3x3<MT, NT, 1>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 1>), grid, dim3(256), lds, st, a); }
+  if (vw == 4) { set((const void*)k_conv3x3<MT, NT, 4>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 4>), grid, dim3(NTHR), lds, st, a); }
+  else if (vw == 2) { set((const void*)k_conv3x3<MT, NT, 2>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 2>), grid, dim3(NTHR), lds, st, a); }
+  else { set((const void*)k_conv3x3<MT, NT, 1>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 1>), grid, dim3(NTHR), lds, st, a); }
   return check_launch("fdet_conv3x3");
 }
 
 int run_conv(ConvArgs a, hipStream_t st) {
   a.WP = a.W + 1;
   a.VR = a.N * (a.H + 1) + 1;
+  if (a.VR >= (1 << 20)) return fail(FDET_EINVAL, "conv3x3: N*(H+1)=%d virtual rows exceed the index range", a.VR);
   a.CoP = (a.Cout + 31) / 32 * 32;
-  const int MT = (a.CoP % 64 == 0) ? 2 : 1;
-  // choose NT (N tiles per wave) so that the launch has enough workgroups for 256 CUs
-  const long total_q = (long)a.VR * a.WP;
-  int NT = 4;
-  while (NT > 1 && total_q / (4L * NT * 32) < 1024) NT >>= 1;
+  const int vw = (a.W % 4 == 0) ? 4 : (a.W % 2 == 0 ? 2 : 1);
+  const int wv = a.W / vw;
+  int lpr_log2 = 0;
+  while ((1 << lpr_log2) < wv) ++lpr_log2;
+  if ((1 << lpr_log2) > NTHR) return fail(FDET_EINVAL, "conv3x3: W=%d too wide", a.W);
+  // choose (MT, NT): every SIMD hosts waves of MT*NT tile-jobs; time ~ ceil(waves/1024) * MT*NT.
+  // Ties -> larger tiles (more operand reuse per LDS byte).
+  const int rows_total = a.VR - 1;             // the last virtual row is a zero row
+  int bestNT = 0, bestMT = 0, bestR = 0; long bestT = 0;
+  int forceMT = 0, forceNT = 0;                 // development override: FDET_CONV_TILE="MT,NT"
+  if (const char* e = getenv("FDET_CONV_TILE")) sscanf(e, "%d,%d", &forceMT, &forceNT);
+  if (const char* e = getenv("FDET_CONV_DBG")) a.dbg = atoi(e);
+  for (int MT = (a.CoP % 64 == 0) ? 2 : 1; MT >= 1; --MT)
+  for (int NT = 4; NT >= 1; NT >>= 1) {
+    if (forceMT && (MT != forceMT || NT != forceNT)) continue;
+    const int cap = 4 * NT * 32;
+    if (a.WP > cap) continue;
+    int R = cap / a.WP;
+    if (R > rows_total) R = rows_total;
+    const int pairs = CK * (R + 2);
+    const int slots = (pairs + (NTHR >> lpr_log2) - 1) / (NTHR >> lpr_log2);
+    if (slots > nbmax(vw)) continue;
+    const size_t lds = (size_t)2 * (CK * 9 * MT * 32 + CK * (cap + 2 * a.WP + 3)) * 4;
+    if (lds > 160 * 1024) continue;
+    const long nb = (rows_total + R - 1) / R;
+    const long waves = nb * (a.CoP / (MT * 32)) * 4;
+    // + a fixed per-wave overhead (prologue, A-panel staging, epilogue) worth ~1.5 tile-jobs
+    const long t = ((waves + 1023) / 1024) * (2 * MT * NT + 3);
+    if (bestNT == 0 || t < bestT) { bestNT = NT; bestMT = MT; bestR = R; bestT = t; }
+  }
+  if (bestNT == 0) return fail(FDET_EINVAL, "conv3x3: no tiling for W=%d H=%d", a.W, a.H);
+  const int NT = bestNT, MT = bestMT;
   const int cap = 4 * NT * 32;
-  if (a.WP > cap) return fail(FDET_EINVAL, "conv3x3: W=%d too wide for the band tiling", a.W);
-  a.R = cap / a.WP;
-  if (a.R > a.VR) a.R = a.VR;
-  a.nbands = (a.VR + a.R - 1) / a.R;
+  a.R = bestR;
+  a.nbands = (rows_total + a.R - 1) / a.R;
   a.CS = cap + 2 * a.WP + 2;
   if ((a.CS & 1) == 0) a.CS += 1;
-  const int vw = (a.W % 4 == 0) ? 4 : (a.W % 2 == 0 ? 2 : 1);
-  const size_t lds = (size_t)(CK * 9 * MT * 32 + CK * a.CS) * 4;
+  a.lpr_log2 = lpr_log2;
+  a.magic_h1 = magic_of(a.H + 1);
+  a.magic_rows = magic_of(a.R + 2);
+  const size_t lds = (size_t)2 * (CK * 9 * MT * 32 + CK * a.CS) * 4;
   dim3 grid(a.nbands, a.CoP / (MT * 32));
   if (MT == 2) {
     if (NT == 4) return launch_conv_vw<2, 4>(a, vw, lds, grid, st);
