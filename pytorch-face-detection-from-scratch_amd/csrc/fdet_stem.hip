@@ -7,8 +7,17 @@
 // (ix+pad = stride*bx + phase) so that the 64 lanes of a wave (consecutive ox) read
 // consecutive dwords for every tap.
 #include "fdet_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 using namespace fdet;
+
+namespace fdet {   // fdet_stem_mfma.hip
+bool stem_mfma_ok(int Cin, int F, int H, int W, int k, int stride, int pad);
+size_t stem_mfma_ws_floats(int N, int F, int H, int W);
+int stem_mfma_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W, hipStream_t st);
+int stem_mfma_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st);
+}
 
 namespace {
 
@@ -191,7 +200,9 @@ bool stem_plan(int N, int Cin, int F, int H, int W, int k, int stride, int pad, 
 extern "C" size_t fdet_stem_ws_bytes(int N, int Cin, int F, int H, int W, int k, int stride, int pad) {
   StemPlan p;
   if (!stem_plan(N, Cin, F, H, W, k, stride, pad, p)) return 0;
-  return p.ws_floats * 4;
+  size_t fl = p.ws_floats;
+  if (stem_mfma_ok(Cin, F, H, W, k, stride, pad)) fl = std::max(fl, stem_mfma_ws_floats(N, F, H, W));
+  return fl * 4;
 }
 
 extern "C" int fdet_stem_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
@@ -201,8 +212,9 @@ extern "C" int fdet_stem_fwd(const float* x, const float* w, const float* bias, 
   FDET_REQUIRE(stem_plan(N, Cin, F, H, W, k, stride, pad, p),
                "stem_fwd: unsupported stem Cin=%d k=%d stride=%d pad=%d W=%d (built: 3ch k10s8p2, k3s2p1)", Cin, k,
                stride, pad, W);
-  if (ws_bytes < p.pack_floats * 4) return fail(FDET_EWORKSPACE, "stem_fwd: workspace %zu < %zu", ws_bytes, p.pack_floats * 4);
   hipStream_t st = (hipStream_t)stream;
+  if (stem_mfma_ok(Cin, F, H, W, k, stride, pad) && !getenv("FDET_STEM_VALU")) return stem_mfma_fwd(x, w, bias, y, N, F, H, W, st);
+  if (ws_bytes < p.pack_floats * 4) return fail(FDET_EWORKSPACE, "stem_fwd: workspace %zu < %zu", ws_bytes, p.pack_floats * 4);
   float* wpk = (float*)ws;
   hipLaunchKernelGGL(k_stem_pack, dim3((p.KK * p.FP + 255) / 256), dim3(256), 0, st, w, F, p.FP, p.KK, wpk);
   dim3 grid(N * p.Ho);
@@ -221,8 +233,12 @@ extern "C" int fdet_stem_wgrad(const float* x, const float* dy, float* dW, float
   FDET_REQUIRE(x && dy && dW && db && ws && N > 0 && F > 0, "stem_wgrad: bad arguments");
   StemPlan p;
   FDET_REQUIRE(stem_plan(N, Cin, F, H, W, k, stride, pad, p), "stem_wgrad: unsupported stem k=%d stride=%d pad=%d", k, stride, pad);
-  if (ws_bytes < p.ws_floats * 4) return fail(FDET_EWORKSPACE, "stem_wgrad: workspace %zu < %zu", ws_bytes, p.ws_floats * 4);
   hipStream_t st = (hipStream_t)stream;
+  if (stem_mfma_ok(Cin, F, H, W, k, stride, pad) && !getenv("FDET_STEM_VALU")) {
+    if (ws_bytes < stem_mfma_ws_floats(N, F, H, W) * 4) return fail(FDET_EWORKSPACE, "stem_wgrad: workspace too small");
+    return stem_mfma_wgrad(x, dy, dW, db, (float*)ws, N, F, H, W, st);
+  }
+  if (ws_bytes < p.ws_floats * 4) return fail(FDET_EWORKSPACE, "stem_wgrad: workspace %zu < %zu", ws_bytes, p.ws_floats * 4);
   float* wsW = (float*)ws + p.pack_floats;
   float* wsb = wsW + (size_t)p.nblk * p.KK * p.FP;
   dim3 grid(p.nblk, p.FP / 64);
