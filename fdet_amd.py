@@ -1,5 +1,6 @@
 """Importable alias of the package directory `pytorch-face-detection-from-scratch_amd/`
-(its name is not a valid Python identifier).  `import fdet_amd` == that package."""
+(its name is not a valid Python identifier).  `import fdet_amd` == that package; submodules
+resolve to the same objects under either name (see the package's alias finder)."""
 import importlib
 import os
 import sys
