@@ -43,7 +43,9 @@ struct ConvArgs {
   float* y_out;          // fwd: z*scale + skip or null
   const float* act;      // dgrad: lrelu' source or null
   int N, Cin, Cout, CoP, H, W, WP, R, VR, CS, nbands, dgrad;
+  int mode;              // EPI_* fusion mode of the epilogue
   int dbg;               // development ablation flags (FDET_CONV_DBG), 0 in production
+  int stagger;           // start delay (x 64*127 clocks) of every second co-resident workgroup
   int lpr_log2;          // log2(lanes per staged row), lanes >= W/VW
   unsigned magic_h1;     // ceil(2^32/(H+1))
   unsigned magic_rows;   // ceil(2^32/(R+2))
@@ -63,6 +65,113 @@ template <> __device__ __forceinline__ float vget<1>(const float& v, int) { retu
 // floor(v/d) for 0 <= v < 2^20, d < 2^12 with magic = ceil(2^32/d); magic == 0 encodes d == 1
 __device__ __forceinline__ int fdiv(int v, unsigned magic) { return magic ? (int)__umulhi((unsigned)v, magic) : v; }
 
+// Fusion modes of the epilogue (host-selected, wave-uniform).  The fast modes assume the channel
+// count is a multiple of 32 and the listed pointers are non-null; everything else is GENERIC.
+enum { EPI_GENERIC = 0,
+       EPI_FWD_FULL,    // y_full = lrelu(acc + bias)
+       EPI_FWD_BOTH,    // y_full = z ; y_out = z*scale + skip        (training, un-pooled block tail)
+       EPI_FWD_OUT,     // y_out = z + skip                          (eval, un-pooled block tail)
+       EPI_DGRAD_ACT,   // dx = acc * lrelu'(act)
+       EPI_DGRAD_ADD }; // dx = acc + add
+
+template <int MT, int NT, int MODE>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const bool (&okn)[NT],
+                                         const size_t (&basen)[NT], const int (&imgn)[NT], int cob0, size_t HW) {
+  const float* __restrict__ g_bias = a.bias;
+  const float* __restrict__ g_skip = a.skip;
+  const float* __restrict__ g_scale = a.scale;
+  const float* __restrict__ g_act = a.act;
+  float* __restrict__ g_full = a.y_full;
+  float* __restrict__ g_out = a.y_out;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int cobase = cob0 + m * 32;                    // + (r&3) + 8*(r>>2)
+    float bz[16];
+    if (MODE == EPI_FWD_FULL || MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bz[r] = g_bias[cobase + (r & 3) + 8 * (r >> 2)];
+    } else if (MODE == EPI_GENERIC) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cobase + (r & 3) + 8 * (r >> 2);
+        bz[r] = (g_bias && co < a.Cout) ? g_bias[co] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      if (!okn[n]) continue;
+      const size_t idx0 = basen[n] + (size_t)cobase * HW;
+      float t0[16], t1[16];
+      if (MODE == EPI_FWD_FULL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float z = acc[m][n][r] + bz[r];
+          g_full[idx0 + ((r & 3) + 8 * (r >> 2)) * HW] = z > 0.f ? z : z * a.slope;
+        }
+      } else if (MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          t0[r] = g_skip[idx0 + cr * HW];
+          if (MODE == EPI_FWD_BOTH) t1[r] = g_scale[(size_t)imgn[n] * a.Cout + cobase + cr];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          float z = acc[m][n][r] + bz[r];
+          z = z > 0.f ? z : z * a.slope;
+          if (MODE == EPI_FWD_BOTH) { g_full[idx0 + cr * HW] = z; g_out[idx0 + cr * HW] = z * t1[r] + t0[r]; }
+          else g_out[idx0 + cr * HW] = z + t0[r];
+        }
+      } else if (MODE == EPI_DGRAD_ACT || MODE == EPI_DGRAD_ADD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          t0[r] = (MODE == EPI_DGRAD_ACT ? g_act : g_skip)[idx0 + ((r & 3) + 8 * (r >> 2)) * HW];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float z = acc[m][n][r];
+          if (MODE == EPI_DGRAD_ACT) z *= (t0[r] > 0.f) ? 1.f : a.slope; else z += t0[r];
+          g_full[idx0 + ((r & 3) + 8 * (r >> 2)) * HW] = z;
+        }
+      } else if (!a.dgrad) {                              // GENERIC forward
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          const bool cok = cobase + cr < a.Cout;
+          t0[r] = (g_out && g_skip && cok) ? g_skip[idx0 + cr * HW] : 0.f;
+          t1[r] = (g_out && g_scale && cok) ? g_scale[(size_t)imgn[n] * a.Cout + cobase + cr] : 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          if (cobase + cr >= a.Cout) continue;
+          float z = acc[m][n][r] + bz[r];
+          z = z > 0.f ? z : z * a.slope;
+          if (g_full) g_full[idx0 + cr * HW] = z;
+          if (g_out) g_out[idx0 + cr * HW] = z * t1[r] + t0[r];
+        }
+      } else {                                            // GENERIC data gradient
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          const bool cok = cobase + cr < a.Cout;
+          t0[r] = (g_act && cok) ? g_act[idx0 + cr * HW] : 1.f;
+          t1[r] = (g_skip && cok) ? g_skip[idx0 + cr * HW] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          if (cobase + cr >= a.Cout) continue;
+          float z = acc[m][n][r];
+          if (g_act) z *= (t0[r] > 0.f) ? 1.f : a.slope;
+          z += t1[r];
+          g_full[idx0 + cr * HW] = z;
+        }
+      }
+    }
+  }
+}
+
 template <int MT, int NT, int VW>
 __global__ void __launch_bounds__(NTHR, 2)
 k_conv3x3(const ConvArgs a) {
@@ -81,6 +190,13 @@ k_conv3x3(const ConvArgs a) {
   const int v0 = band * a.R;
   const int H1 = a.H + 1;
 
+  // Two workgroups share a CU and would otherwise run their prologue / MFMA loop / epilogue in
+  // lockstep; delaying the one in the odd wave slot lets one's epilogue overlap the other's MFMAs.
+  if (a.stagger > 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID bits [3:0] = wave slot
+    if (hwid & 1u)
+      for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   // B halos stay zero for all chunks (staging never touches them)
   for (int t = tid; t < 2 * bufsz; t += NTHR) lds[t] = 0.f;
 
@@ -197,14 +313,8 @@ k_conv3x3(const ConvArgs a) {
     if (!(a.dbg & 8)) __syncthreads();
   }
 
-  // ---- epilogue.  Loads (bias, skip, scale, act) are batched per 32x32 tile ahead of the
-  // stores; the restrict-qualified locals tell the compiler stores cannot feed later loads.
-  const float* __restrict__ g_bias = a.bias;
-  const float* __restrict__ g_skip = a.skip;
-  const float* __restrict__ g_scale = a.scale;
-  const float* __restrict__ g_act = a.act;
-  float* __restrict__ g_full = a.y_full;
-  float* __restrict__ g_out = a.y_out;
+  // ---- epilogue: one uniform switch on the fusion mode, then straight-line code per 32x32 tile:
+  // all loads of a tile (skip / scale / act / add) are issued before its stores.
   const int qlimit = a.R * WP;
   const size_t HW = (size_t)a.H * a.W;
   bool okn[NT];
@@ -220,56 +330,14 @@ k_conv3x3(const ConvArgs a) {
     basen[n] = ((size_t)img * a.Cout * a.H + oy) * a.W + ox;
     imgn[n] = img;
   }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int cobase = mb * MB + m * 32 + 4 * half;      // + (r&3) + 8*(r>>2)
-    float bz[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cobase + (r & 3) + 8 * (r >> 2);
-      bz[r] = (g_bias && co < a.Cout) ? g_bias[co] : 0.f;
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      if (!okn[n]) continue;
-      const size_t idx0 = basen[n] + (size_t)cobase * HW;
-      float t0[16], t1[16];
-      if (!a.dgrad) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cr = (r & 3) + 8 * (r >> 2);
-          const bool cok = cobase + cr < a.Cout;
-          t0[r] = (g_out && g_skip && cok) ? g_skip[idx0 + cr * HW] : 0.f;
-          t1[r] = (g_out && g_scale && cok) ? g_scale[(size_t)imgn[n] * a.Cout + cobase + cr] : 1.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cr = (r & 3) + 8 * (r >> 2);
-          if (cobase + cr >= a.Cout) continue;
-          float z = acc[m][n][r] + bz[r];
-          z = z > 0.f ? z : z * a.slope;
-          if (g_full) g_full[idx0 + cr * HW] = z;
-          if (g_out) g_out[idx0 + cr * HW] = z * t1[r] + t0[r];
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cr = (r & 3) + 8 * (r >> 2);
-          const bool cok = cobase + cr < a.Cout;
-          t0[r] = (g_act && cok) ? g_act[idx0 + cr * HW] : 1.f;
-          t1[r] = (g_skip && cok) ? g_skip[idx0 + cr * HW] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cr = (r & 3) + 8 * (r >> 2);
-          if (cobase + cr >= a.Cout) continue;
-          float z = acc[m][n][r];
-          if (g_act) z *= (t0[r] > 0.f) ? 1.f : a.slope;
-          z += t1[r];
-          g_full[idx0 + cr * HW] = z;
-        }
-      }
-    }
+  const int cob0 = mb * MB + 4 * half;
+  switch (a.mode) {
+    case EPI_FWD_FULL: epilogue<MT, NT, EPI_FWD_FULL>(a, acc, okn, basen, imgn, cob0, HW); break;
+    case EPI_FWD_BOTH: epilogue<MT, NT, EPI_FWD_BOTH>(a, acc, okn, basen, imgn, cob0, HW); break;
+    case EPI_FWD_OUT: epilogue<MT, NT, EPI_FWD_OUT>(a, acc, okn, basen, imgn, cob0, HW); break;
+    case EPI_DGRAD_ACT: epilogue<MT, NT, EPI_DGRAD_ACT>(a, acc, okn, basen, imgn, cob0, HW); break;
+    case EPI_DGRAD_ADD: epilogue<MT, NT, EPI_DGRAD_ADD>(a, acc, okn, basen, imgn, cob0, HW); break;
+    default: epilogue<MT, NT, EPI_GENERIC>(a, acc, okn, basen, imgn, cob0, HW); break;
   }
 }
 
@@ -300,6 +368,7 @@ int launch_conv_vw(const ConvArgs& a, int vw, size_t lds, dim3 grid, hipStream_t
   auto set = [&](const void* f) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   };
+
   if (vw == 4) { set((const void*)k_conv3x3<MT, NT, 4>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 4>), grid, dim3(NTHR), lds, st, a); }
   else if (vw == 2) { set((const void*)k_conv3x3<MT, NT, 2>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 2>), grid, dim3(NTHR), lds, st, a); }
   else { set((const void*)k_conv3x3<MT, NT, 1>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 1>), grid, dim3(NTHR), lds, st, a); }
@@ -309,6 +378,17 @@ int launch_conv_vw(const ConvArgs& a, int vw, size_t lds, dim3 grid, hipStream_t
 int run_conv(ConvArgs a, hipStream_t st) {
   a.WP = a.W + 1;
   a.VR = a.N * (a.H + 1) + 1;
+  a.mode = EPI_GENERIC;
+  if (a.Cout % 32 == 0) {
+    if (!a.dgrad && a.bias) {
+      if (a.y_full && !a.y_out) a.mode = EPI_FWD_FULL;
+      else if (a.y_full && a.y_out && a.skip && a.scale) a.mode = EPI_FWD_BOTH;
+      else if (!a.y_full && a.y_out && a.skip && !a.scale) a.mode = EPI_FWD_OUT;
+    } else if (a.dgrad) {
+      if (a.act && !a.skip) a.mode = EPI_DGRAD_ACT;
+      else if (!a.act && a.skip) a.mode = EPI_DGRAD_ADD;
+    }
+  }
   if (a.VR >= (1 << 20)) return fail(FDET_EINVAL, "conv3x3: N*(H+1)=%d virtual rows exceed the index range", a.VR);
   a.CoP = (a.Cout + 31) / 32 * 32;
   const int vw = (a.W % 4 == 0) ? 4 : (a.W % 2 == 0 ? 2 : 1);
@@ -323,6 +403,7 @@ int run_conv(ConvArgs a, hipStream_t st) {
   int forceMT = 0, forceNT = 0;                 // development override: FDET_CONV_TILE="MT,NT"
   if (const char* e = getenv("FDET_CONV_TILE")) sscanf(e, "%d,%d", &forceMT, &forceNT);
   if (const char* e = getenv("FDET_CONV_DBG")) a.dbg = atoi(e);
+  if (const char* e = getenv("FDET_CONV_STAGGER")) a.stagger = atoi(e);
   for (int MT = (a.CoP % 64 == 0) ? 2 : 1; MT >= 1; --MT)
   for (int NT = 4; NT >= 1; NT >>= 1) {
     if (forceMT && (MT != forceMT || NT != forceNT)) continue;

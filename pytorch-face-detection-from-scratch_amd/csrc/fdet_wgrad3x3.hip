@@ -12,6 +12,7 @@
 // At the end each (workgroup, kh) writes one slab; a second kernel sums the slabs in fixed
 // order (deterministic, no float atomics).
 #include "fdet_common.h"
+#include <algorithm>
 
 using namespace fdet;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -184,19 +185,45 @@ k_wgrad3x3(const WgArgs a) {
     }
   }
 
-  // ---- write slab: ws[s][tap][co][ci], wsb[s][co]
-  const int s = blockIdx.x * KS + kh;
+  // ---- combine the K splits of this workgroup through LDS (staging tiles are dead now), then
+  //      the kh == 0 waves write ONE slab per workgroup: ws[blk][tap][co][ci], wsb[blk][co]
+  bsum += __shfl_xor(bsum, 32, 64);
+  {
+    float* red = reinterpret_cast<float*>(smem);          // [MTC*CG][9*16][64] + [MTC*CG][64]
+    const int role = wid % (MTC * CG);
+#pragma unroll 1
+    for (int rnd = 1; rnd < KS; ++rnd) {
+      __syncthreads();
+      if (kh == rnd) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int ci = ci0 + cg * 32 + l31;
-      a.ws[(((size_t)s * 9 + t) * a.CoP + co) * a.CiP + ci] = acc[t][r];
+          for (int r = 0; r < 16; ++r) red[(role * 144 + t * 16 + r) * 64 + lane] = acc[t][r];
+        red[MTC * CG * 144 * 64 + role * 64 + lane] = bsum;
+      }
+      __syncthreads();
+      if (kh == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += red[(role * 144 + t * 16 + r) * 64 + lane];
+        bsum += red[MTC * CG * 144 * 64 + role * 64 + lane];
+      }
     }
   }
-  bsum += __shfl_xor(bsum, 32, 64);
-  if (cib == 0 && cg == 0 && half == 0) a.wsb[(size_t)s * a.CoP + co0 + m * 32 + l31] = bsum;
+  if (kh == 0) {
+    const int s = blockIdx.x;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ci = ci0 + cg * 32 + l31;
+        a.ws[(((size_t)s * 9 + t) * a.CoP + co) * a.CiP + ci] = acc[t][r];
+      }
+    }
+    if (cib == 0 && cg == 0 && half == 0) a.wsb[(size_t)s * a.CoP + co0 + m * 32 + l31] = bsum;
+  }
 }
 
 struct WgArgsG {
@@ -316,37 +343,41 @@ k_wgrad3x3_generic(const WgArgsG a) {
 }
 
 
-// Fixed-order reduction of the slabs.  One workgroup per (tap, co): 64-thread rows of ci,
-// four slab phases, then an LDS combine in phase order.
-__global__ void __launch_bounds__(256)
+// Fixed-order reduction of the slabs.  One workgroup (1024 threads) per (tap, 4 output
+// channels): 256 consecutive floats of every slab, four slab phases, LDS combine in phase order.
+__global__ void __launch_bounds__(1024)
 k_wgrad3x3_reduce(const float* __restrict__ ws, const float* __restrict__ wsb, int nslab, int Cout, int Cin,
                   int CoP, int CiP, float* __restrict__ dW, float* __restrict__ db) {
-  __shared__ float part[256];
-  const int tap = blockIdx.x, co = blockIdx.y;
-  const int cil = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  for (int c0 = 0; c0 < CiP; c0 += 64) {
-    const int ci = c0 + cil;
+  __shared__ float part[1024];
+  const int tap = blockIdx.x;
+  const int e = threadIdx.x & 255, ph = threadIdx.x >> 8;
+  const int span = 4 * CiP;                               // floats per (slab, tap, 4 channels)
+  const int co0 = blockIdx.y * 4;
+  for (int e0 = 0; e0 < span; e0 += 256) {
+    const int idx = e0 + e;
     float s = 0.f;
-    if (ci < CiP)
-      for (int k = ph; k < nslab; k += 4) s += ws[(((size_t)k * 9 + tap) * CoP + co) * CiP + ci];
+    if (idx < span && co0 + idx / CiP < CoP) {
+      const float* src = ws + ((size_t)tap * CoP + co0) * CiP + idx;
+#pragma unroll 4
+      for (int k = ph; k < nslab; k += 4) s += src[(size_t)k * 9 * CoP * CiP];
+    }
     part[threadIdx.x] = s;
     __syncthreads();
-    if (ph == 0 && ci < Cin) {
-      const float tot = ((part[cil] + part[64 + cil]) + part[128 + cil]) + part[192 + cil];
-      dW[((size_t)co * Cin + ci) * 9 + tap] = tot;
+    if (ph == 0 && idx < span) {
+      const int co = co0 + idx / CiP, ci = idx % CiP;
+      if (co < Cout && ci < Cin)
+        dW[((size_t)co * Cin + ci) * 9 + tap] = ((part[e] + part[256 + e]) + part[512 + e]) + part[768 + e];
     }
     __syncthreads();
   }
-  if (db && tap == 0) {
+  if (db && tap == 0 && threadIdx.x < 4 * 64) {
+    // 4 channels x 64 slab lanes
+    const int c = threadIdx.x >> 6, ln = threadIdx.x & 63;
     float s = 0.f;
-    for (int k = threadIdx.x; k < nslab; k += 256) s += wsb[(size_t)k * CoP + co];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-      if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) db[co] = part[0];
+    if (co0 + c < Cout)
+      for (int k = ln; k < nslab; k += 64) s += wsb[(size_t)k * CoP + co0 + c];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (ln == 0 && co0 + c < Cout) db[co0 + c] = s;
   }
 }
 
@@ -385,8 +416,9 @@ WgPlan plan_wgrad(int N, int Cin, int Cout, int H, int W) {
   p.CSX = (p.R + 2) * p.WP + 10; if ((p.CSX & 1) == 0) p.CSX += 1;
   p.nbands = (rows_total + p.R - 1) / p.R;
   p.nblk = p.nbands < 256 ? p.nbands : 256;
-  p.nslab = p.nblk * p.KS;
+  p.nslab = p.nblk;                                   // K splits are combined inside the workgroup
   p.lds = ((size_t)p.MTC * 32 * p.CSZ + (size_t)p.CG * 32 * p.CSX) * 4;
+  if (p.KS > 1) p.lds = std::max(p.lds, (size_t)p.MTC * p.CG * (144 + 1) * 64 * 4);
   p.ws_floats = (size_t)p.nslab * 9 * p.CoP * p.CiP + (size_t)p.nslab * p.CoP;
   return p;
 }
@@ -459,7 +491,7 @@ extern "C" int fdet_conv3x3_wgrad(const float* x, const float* dz, float* dW, fl
     else if (p.CG == 2) launch_wg<1, 2>(a, p, grid, st);
     else launch_wg<1, 1>(a, p, grid, st);
     if (int rc = check_launch("fdet_conv3x3_wgrad")) return rc;
-    hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3(9, Cout), dim3(256), 0, st, a.ws, a.wsb, p.nslab, Cout, Cin, p.CoP,
+    hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3(9, (Cout + 3) / 4), dim3(1024), 0, st, a.ws, a.wsb, p.nslab, Cout, Cin, p.CoP,
                        p.CiP, dW, db);
     return check_launch("fdet_conv3x3_wgrad(reduce)");
   }
@@ -481,7 +513,7 @@ extern "C" int fdet_conv3x3_wgrad(const float* x, const float* dz, float* dW, fl
     hipLaunchKernelGGL(k_wgrad3x3_generic<1>, grid, dim3(256), g.lds, st, a);
   }
   if (int rc = check_launch("fdet_conv3x3_wgrad(generic)")) return rc;
-  hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3(9, Cout), dim3(256), 0, st, a.ws, a.wsb, g.nslab, Cout, Cin, g.CoP,
+  hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3(9, (Cout + 3) / 4), dim3(1024), 0, st, a.ws, a.wsb, g.nslab, Cout, Cin, g.CoP,
                      g.CiP, dW, db);
   return check_launch("fdet_conv3x3_wgrad(reduce)");
 }

@@ -33,6 +33,8 @@ if os.path.exists(peak):
         print(f"mfma_f32_32x32x2 peak probe blocks={blocks}: {ms:.3f} ms -> {fl/ms/1e9:.1f} TFLOP/s")
     rnd = torch.randn(4096, device="cuda") * 0.01
     ms = timeit(lambda: L.probe_peak_rand(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(rnd.data_ptr()), 2048, 2000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 5)
+    ms2 = timeit(lambda: L.probe_peak_lds(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(rnd.data_ptr()), 2048, 2000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 5)
+    print(f"mfma_f32_32x32x2 + LDS operand reads (conv pattern, random): {ms2:.3f} ms -> {2048*4*2000*8*32*32*2*2/ms2/1e9:.1f} TFLOP/s")
     print(f"mfma_f32_32x32x2 peak probe RANDOM operands: {ms:.3f} ms -> {2048*4*2000*8*32*32*2*2/ms/1e9:.1f} TFLOP/s")
 
 for H in (60, 30, 15):

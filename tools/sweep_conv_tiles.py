@@ -24,10 +24,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(res))
 else:
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    cfgs = [(2, 4, d) for d in (0, 1, 2, 4, 6, 14, 15)] + [(2, 2, d) for d in (0, 1, 15)]
+    cfgs = [(2, 4, st) for st in (0, 2, 5, 10, 20)] + [(2, 2, st) for st in (0, 2, 5, 10)] + [(1, 2, st) for st in (0, 1, 2, 4, 8)] + [(2, 1, st) for st in (0, 2, 4)]
     for mt, nt, dbg in cfgs:
         if True:
-            env = dict(os.environ, FDET_CONV_TILE=f"{mt},{nt}", FDET_CONV_DBG=str(dbg))
+            env = dict(os.environ, FDET_CONV_TILE=f"{mt},{nt}", FDET_CONV_STAGGER=str(dbg))
             r = subprocess.run([sys.executable, __file__, "child", str(N)], env=env, capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            print(f"MT={mt} NT={nt} dbg={dbg}:", line[-1] if line else r.stderr[-300:], flush=True)
+            print(f"MT={mt} NT={nt} stagger={dbg}:", line[-1] if line else r.stderr[-300:], flush=True)
