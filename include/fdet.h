@@ -149,6 +149,20 @@ int fdet_conv3x3_fwd(const float* x, const float* wpk, const float* bias, float*
 int fdet_conv3x3_dgrad(const float* dz, const float* wpk, const float* act, const float* add,
                        float* dx, int N, int Cin, int Cout, int H, int W, float slope, void* stream);
 
+/* bf16x3 variants of the three entry points above: identical arguments and results within ~1e-5
+ * (tests: 1e-4), computed on v_mfma_f32_32x32x16_bf16 with every fp32 operand split into two
+ * bf16 values (x = hi + lo; products a_hi*b_lo + a_lo*b_hi + a_hi*b_hi, fp32 accumulation).
+ * ~5x the MFMA rate of the fp32 path: the convs become HBM-bound.  Channel counts must be
+ * multiples of 16.  The packed panels hold [hi | lo] bf16 and are EXACTLY as large as the fp32
+ * panels (same buffers can be reused); they are not interchangeable with them. */
+int fdet_pack_conv3x3_weights_bf16x3(const float* w, int Cout, int Cin, void* wpk_fwd, void* wpk_bwd,
+                                     void* stream);
+int fdet_conv3x3_fwd_bf16x3(const float* x, const void* wpk, const float* bias, float* y_full,
+                            const float* skip, const float* drop_scale, float* y_out,
+                            int N, int Cin, int Cout, int H, int W, int pool, float slope, void* stream);
+int fdet_conv3x3_dgrad_bf16x3(const float* dz, const void* wpk, const float* act, const float* add,
+                              float* dx, int N, int Cin, int Cout, int H, int W, float slope, void* stream);
+
 /* Weight + bias gradient of the 3x3 conv: dW[co,ci,ky,kx] = sum_{n,y,x} dz*x_shifted,
  * db[co] = sum dz.  Deterministic two-pass (per-workgroup slabs in `ws`, then a fixed-order
  * reduce).  dW [Cout,Cin,3,3], db [Cout] are overwritten. */

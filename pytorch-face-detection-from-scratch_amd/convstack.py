@@ -118,6 +118,12 @@ class ConvStack:
         self._ws: Dict[str, torch.Tensor] = {}
         self.slope = 0.2
         self.timer: Optional[KernelTimer] = None
+        # conv arithmetic: "bf16x3" (bf16 hi/lo split on the bf16 matrix cores, fp32 accumulate,
+        # ~1e-5 of fp32) where the channel count allows, else "f32" (exact fp32 MFMA chain).
+        # FDET_PRECISION=f32 forces the exact path.
+        import os
+        want = os.environ.get("FDET_PRECISION", "bf16x3")
+        self.x3 = (want == "bf16x3") and hp.x3_supported(geo.filters, geo.filters)
 
     def _t(self, kind: str, N: int, h: int, flops: float = 0.0, nbytes: float = 0.0):
         if self.timer is None:
@@ -130,7 +136,7 @@ class ConvStack:
 
     # ------------------------------------------------------------------ weights
     def _ensure_packed(self, P: Dict[str, torch.Tensor], force: bool = False):
-        key = tuple((P[k].data_ptr(), P[k]._version) for k in sorted(P) if k.endswith("weight"))
+        key = (self.x3,) + tuple((P[k].data_ptr(), P[k]._version) for k in sorted(P) if k.endswith("weight"))
         if not force and key == self._packed_key:
             return
         F_ = self.geo.filters
@@ -142,7 +148,7 @@ class ConvStack:
                 if name + ".f" not in self._wpk:
                     self._wpk[name + ".f"] = torch.empty(nf, dtype=F32, device=dev)
                     self._wpk[name + ".b"] = torch.empty(nb, dtype=F32, device=dev)
-                hp.pack_conv3x3_weights(P[name + ".weight"], self._wpk[name + ".f"], self._wpk[name + ".b"])
+                hp.pack_conv3x3_weights(P[name + ".weight"], self._wpk[name + ".f"], self._wpk[name + ".b"], x3=self.x3)
         self._packed_key = key
 
     def mark_params_dirty(self):
@@ -181,19 +187,19 @@ class ConvStack:
             sc = masks[name] if masks is not None else None
             a = torch.empty(N, F_, hk, hk, dtype=F32, device=dev)
             with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk)):
-                hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], F_, y_full=a, slope=self.slope)
+                hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], F_, y_full=a, slope=self.slope, x3=self.x3)
             out = torch.empty(N, F_, hk // pool, hk // pool, dtype=F32, device=dev)
             if pool == 2:
                 c = torch.empty_like(a)
                 with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk)):
-                    hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, slope=self.slope)
+                    hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, slope=self.slope, x3=self.x3)
                 with self._t("tail_fwd", N, hk):
                     hp.block_tail_fwd(c, h, sc, out, 2)
             else:
                 c = torch.empty_like(a) if save else None
                 with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk)):
                     hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, skip=h,
-                                   drop_scale=sc, y_out=out, slope=self.slope)
+                                   drop_scale=sc, y_out=out, slope=self.slope, x3=self.x3)
             if save:
                 saved["blocks"].append((h, a, c))
             h = out
@@ -242,12 +248,12 @@ class ConvStack:
                 hp.conv3x3_wgrad(a, dz2, G[name + ".conv2.weight"], G[name + ".conv2.bias"], wws)
             dz1 = torch.empty_like(a)
             with self._t("conv3x3_dgrad", N, hk, fl):
-                hp.conv3x3_dgrad(dz2, self._wpk[name + ".conv2.b"], F_, dz1, act=a, slope=self.slope)
+                hp.conv3x3_dgrad(dz2, self._wpk[name + ".conv2.b"], F_, dz1, act=a, slope=self.slope, x3=self.x3)
             with self._t("conv3x3_wgrad", N, hk, fl):
                 hp.conv3x3_wgrad(xin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], wws)
             dx = dz2                                   # reuse: dz2 is dead after its wgrad/dgrad
             with self._t("conv3x3_dgrad", N, hk, fl):
-                hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], F_, dx, add=de, slope=self.slope)
+                hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], F_, dx, add=de, slope=self.slope, x3=self.x3)
             dout = dx
             if after_block is not None:
                 after_block(k)

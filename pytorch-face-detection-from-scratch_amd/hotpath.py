@@ -166,7 +166,14 @@ def packed_sizes(cout: int, cin: int) -> Tuple[int, int]:
     return cin * 9 * cop, cout * 9 * cip
 
 
-def pack_conv3x3_weights(w: torch.Tensor, wpk_fwd: Optional[torch.Tensor], wpk_bwd: Optional[torch.Tensor]) -> None:
+def x3_supported(cout: int, cin: int) -> bool:
+    """bf16x3 conv kernels need channel counts that are multiples of 16."""
+    return cout % 16 == 0 and cin % 16 == 0
+
+
+def pack_conv3x3_weights(w: torch.Tensor, wpk_fwd: Optional[torch.Tensor], wpk_bwd: Optional[torch.Tensor],
+                         x3: bool = False) -> None:
+    """x3=True packs the bf16 hi/lo panels of the bf16x3 kernels (same buffer sizes)."""
     cout, cin, kh, kw = w.shape
     if (kh, kw) != (3, 3):
         raise ValueError("pack_conv3x3_weights: 3x3 kernels only")
@@ -175,11 +182,12 @@ def pack_conv3x3_weights(w: torch.Tensor, wpk_fwd: Optional[torch.Tensor], wpk_b
         raise ValueError(f"wpk_fwd must hold {nf} floats")
     if wpk_bwd is not None and wpk_bwd.numel() != nb:
         raise ValueError(f"wpk_bwd must hold {nb} floats")
-    check(lib().fdet_pack_conv3x3_weights(ptr(w), cout, cin, ptr(wpk_fwd), ptr(wpk_bwd), stream()),
-          "fdet_pack_conv3x3_weights")
+    fn = lib().fdet_pack_conv3x3_weights_bf16x3 if x3 else lib().fdet_pack_conv3x3_weights
+    check(fn(ptr(w), cout, cin, ptr(wpk_fwd), ptr(wpk_bwd), stream()), "fdet_pack_conv3x3_weights")
 
 
-def conv3x3_fwd(x, wpk, bias, cout: int, y_full=None, skip=None, drop_scale=None, y_out=None, slope: float = 0.2):
+def conv3x3_fwd(x, wpk, bias, cout: int, y_full=None, skip=None, drop_scale=None, y_out=None, slope: float = 0.2,
+                x3: bool = False):
     Nn, cin, H, W = x.shape
     if wpk.numel() != packed_sizes(cout, cin)[0]:
         raise ValueError("conv3x3_fwd: packed weight size does not match (Cout,Cin)")
@@ -190,11 +198,12 @@ def conv3x3_fwd(x, wpk, bias, cout: int, y_full=None, skip=None, drop_scale=None
         _chk4(bias, (cout,), "bias")
     if drop_scale is not None:
         _chk4(drop_scale, (Nn, cout), "drop_scale")
-    check(lib().fdet_conv3x3_fwd(ptr(x), ptr(wpk), ptr(bias), ptr(y_full), ptr(skip), ptr(drop_scale), ptr(y_out),
-                                 Nn, cin, cout, H, W, 1, float(slope), stream()), "fdet_conv3x3_fwd")
+    fn = lib().fdet_conv3x3_fwd_bf16x3 if x3 else lib().fdet_conv3x3_fwd
+    check(fn(ptr(x), ptr(wpk), ptr(bias), ptr(y_full), ptr(skip), ptr(drop_scale), ptr(y_out),
+             Nn, cin, cout, H, W, 1, float(slope), stream()), "fdet_conv3x3_fwd")
 
 
-def conv3x3_dgrad(dz, wpk_bwd, cin: int, dx, act=None, add=None, slope: float = 0.2):
+def conv3x3_dgrad(dz, wpk_bwd, cin: int, dx, act=None, add=None, slope: float = 0.2, x3: bool = False):
     Nn, cout, H, W = dz.shape
     if wpk_bwd.numel() != packed_sizes(cout, cin)[1]:
         raise ValueError("conv3x3_dgrad: packed weight size does not match (Cout,Cin)")
@@ -202,8 +211,9 @@ def conv3x3_dgrad(dz, wpk_bwd, cin: int, dx, act=None, add=None, slope: float = 
     for t, nm in ((act, "act"), (add, "add")):
         if t is not None:
             _chk4(t, (Nn, cin, H, W), nm)
-    check(lib().fdet_conv3x3_dgrad(ptr(dz), ptr(wpk_bwd), ptr(act), ptr(add), ptr(dx), Nn, cin, cout, H, W,
-                                   float(slope), stream()), "fdet_conv3x3_dgrad")
+    fn = lib().fdet_conv3x3_dgrad_bf16x3 if x3 else lib().fdet_conv3x3_dgrad
+    check(fn(ptr(dz), ptr(wpk_bwd), ptr(act), ptr(add), ptr(dx), Nn, cin, cout, H, W, float(slope), stream()),
+          "fdet_conv3x3_dgrad")
 
 
 def conv3x3_wgrad_ws_bytes(Nn, cin, cout, H, W) -> int:

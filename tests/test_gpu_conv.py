@@ -26,9 +26,14 @@ SHAPES = [(3, 64, 60, 60), (5, 64, 15, 15), (4, 64, 30, 30), (2, 32, 30, 30), (2
           (2, 128, 15, 15), (33, 64, 15, 15)]
 
 
+@pytest.mark.parametrize("x3", [False, True], ids=["f32", "bf16x3"])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_conv3x3_fwd_dgrad_wgrad(hp, shape):
+def test_conv3x3_fwd_dgrad_wgrad(hp, shape, x3):
+    """x3=False: exact fp32 MFMA chain.  x3=True: bf16 hi/lo split on the bf16 matrix cores with
+    fp32 accumulation; same 1e-4 tolerance (observed ~1e-5)."""
     N, C, H, W = shape
+    if x3 and not hp.x3_supported(C, C):
+        pytest.skip("bf16x3 needs channel counts that are multiples of 16")
     g = torch.Generator().manual_seed(N * 1000 + C + H)
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(C, C, 3, 3, generator=g) * 0.1
@@ -37,23 +42,34 @@ def test_conv3x3_fwd_dgrad_wgrad(hp, shape):
     scale = (torch.rand(N, C, generator=g) > 0.25).float() / 0.75
     nf, nb = hp.packed_sizes(C, C)
     wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda")
-    hp.pack_conv3x3_weights(w.cuda(), wf, wb)
+    hp.pack_conv3x3_weights(w.cuda(), wf, wb, x3=x3)
     xd = x.cuda()
     # forward, conv1 flavour and conv2 flavour
     y_full = torch.full((N, C, H, W), float("nan"), device="cuda")
     y_out = torch.full((N, C, H, W), float("nan"), device="cuda")
-    hp.conv3x3_fwd(xd, wf, b.cuda(), C, y_full=y_full, skip=skip.cuda(), drop_scale=scale.cuda(), y_out=y_out)
+    hp.conv3x3_fwd(xd, wf, b.cuda(), C, y_full=y_full, skip=skip.cuda(), drop_scale=scale.cuda(), y_out=y_out, x3=x3)
+    y1 = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.conv3x3_fwd(xd, wf, b.cuda(), C, y_full=y1, x3=x3)                       # conv1 flavour (own epilogue mode)
+    y2 = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.conv3x3_fwd(xd, wf, b.cuda(), C, skip=skip.cuda(), y_out=y2, x3=x3)      # eval block tail
     z = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
     close(y_full, z)
     close(y_out, z * scale[:, :, None, None] + skip)
+    close(y1, z)
+    close(y2, z + skip)
     # data gradient with fused lrelu' and add
     dz = torch.randn(N, C, H, W, generator=g)
     act = torch.randn(N, C, H, W, generator=g)
     add = torch.randn(N, C, H, W, generator=g)
     dx = torch.full((N, C, H, W), float("nan"), device="cuda")
-    hp.conv3x3_dgrad(dz.cuda(), wb, C, dx, act=act.cuda(), add=add.cuda())
+    hp.conv3x3_dgrad(dz.cuda(), wb, C, dx, act=act.cuda(), add=add.cuda(), x3=x3)
     ref = F.conv_transpose2d(dz, w, padding=1) * torch.where(act > 0, 1.0, 0.2) + add
     close(dx, ref)
+    dxa = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.conv3x3_dgrad(dz.cuda(), wb, C, dxa, act=act.cuda(), x3=x3)
+    close(dxa, F.conv_transpose2d(dz, w, padding=1) * torch.where(act > 0, 1.0, 0.2))
+    hp.conv3x3_dgrad(dz.cuda(), wb, C, dxa, add=add.cuda(), x3=x3)
+    close(dxa, F.conv_transpose2d(dz, w, padding=1) + add)
     # weight gradient
     ws = torch.empty(hp.conv3x3_wgrad_ws_bytes(N, C, C, H, W) // 4, device="cuda")
     dW = torch.full((C, C, 3, 3), float("nan"), device="cuda"); db = torch.full((C,), float("nan"), device="cuda")

