@@ -170,6 +170,13 @@ size_t fdet_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int fdet_conv3x3_wgrad(const float* x, const float* dz, float* dW, float* db, void* ws,
                        size_t ws_bytes, int N, int Cin, int Cout, int H, int W, void* stream);
 
+/* bf16x3 variant of the weight gradient (same arguments/results within ~1e-5 of the tensor's scale;
+ * see the bf16x3 note above).  Needs W/VW <= 16 lanes per row (VW = 4, 2, 1 for W%4==0, W%2==0, else):
+ * W <= 64; fdet_conv3x3_wgrad_bf16x3_ws_bytes returns 0 when the shape is not supported. */
+size_t fdet_conv3x3_wgrad_bf16x3_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int fdet_conv3x3_wgrad_bf16x3(const float* x, const float* dz, float* dW, float* db, void* ws,
+                              size_t ws_bytes, int N, int Cin, int Cout, int H, int W, void* stream);
+
 /* Residual-block tail for pooled blocks: out = maxpool_pool(c*drop_scale[n,f] + x)
  * (Dropout2d + skip add + MaxPool2d(2), models/PoolResnet.py:39-42).  pool in {1,2}.
  *   c,x [N,F,H,W]; drop_scale [N,F] or NULL; out [N,F,H/pool,W/pool]. */

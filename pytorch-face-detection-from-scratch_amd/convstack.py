@@ -244,13 +244,14 @@ class ConvStack:
                 de = dout
             fl = self._conv_flops(N, hk)
             wws = self._workspace("wgrad", hp.conv3x3_wgrad_ws_bytes(N, F_, F_, hk, hk), dev)
+            wx3 = self.x3 and hp.wgrad_x3_supported(N, F_, F_, hk, hk)
             with self._t("conv3x3_wgrad", N, hk, fl):
-                hp.conv3x3_wgrad(a, dz2, G[name + ".conv2.weight"], G[name + ".conv2.bias"], wws)
+                hp.conv3x3_wgrad(a, dz2, G[name + ".conv2.weight"], G[name + ".conv2.bias"], wws, x3=wx3)
             dz1 = torch.empty_like(a)
             with self._t("conv3x3_dgrad", N, hk, fl):
                 hp.conv3x3_dgrad(dz2, self._wpk[name + ".conv2.b"], F_, dz1, act=a, slope=self.slope, x3=self.x3)
             with self._t("conv3x3_wgrad", N, hk, fl):
-                hp.conv3x3_wgrad(xin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], wws)
+                hp.conv3x3_wgrad(xin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], wws, x3=wx3)
             dx = dz2                                   # reuse: dz2 is dead after its wgrad/dgrad
             with self._t("conv3x3_dgrad", N, hk, fl):
                 hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], F_, dx, add=de, slope=self.slope, x3=self.x3)

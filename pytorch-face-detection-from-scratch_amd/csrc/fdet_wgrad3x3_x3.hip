@@ -1,0 +1,400 @@
+// Weight/bias gradient of the 3x3 convs on the bf16 matrix cores with fp32-level accuracy
+// (bf16x3: x = hi + lo, products a_hi*b_lo + a_lo*b_hi + a_hi*b_hi, fp32 accumulation).
+//
+//   dW[co][ci][ky][kx] = sum_q dz[co][q] * x[ci][q + ky*P + kx - 1]          (P = row pitch)
+// The MFMA K index is 16 consecutive POSITIONS, so a lane's fragment is 8 consecutive bf16 of one
+// channel row = one aligned 16-byte LDS read -- as long as the start is a multiple of 8.  The row
+// pitch P is a multiple of 8, which keeps the ky shifts aligned; the +-1 element kx shifts are
+// moved onto the dz operand (u = q + kx - 1  ->  dz[u - kx + 1]) and done in registers:
+// kx=1 reads the aligned chunk, kx=0 / kx=2 are a one-element funnel shift (v_alignbyte) of two
+// neighbouring chunks.  So per 16-position step a wave issues 12 ds_read_b128, 16 v_alignbyte and
+// 27 MFMAs (9 taps x 3 split products).
+//
+// Tiles (bf16 hi and lo): dz [64 co][QZ], x [32 ci][PX]; a band = R virtual rows (256 positions);
+// the fp32 -> (hi,lo) split happens while staging global -> registers -> LDS, the next band is
+// prefetched during the MFMAs.  One workgroup (4 waves: co tile x K half) per CU and ci group,
+// persistent over bands; K halves are combined in LDS, slabs reduced in fixed order.
+#include "fdet_common.h"
+#include <algorithm>
+
+using namespace fdet;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NTHR = 256;
+constexpr int ZP = 16;        // front pad (elements) of the dz rows
+constexpr int XP = 8;         // front pad of the x rows
+// prefetch register budget (dz tile, x tile); the scalar-load layout (odd W) gets less because
+// every load carries its own address registers
+__host__ __device__ constexpr int zreg(int vw) { return vw == 1 ? 32 : 64; }
+__host__ __device__ constexpr int xreg(int vw) { return vw == 1 ? 40 : 64; }
+
+struct WgX3Args {
+  const float* x;    // [N,Cin,H,W]
+  const float* dz;   // [N,Cout,H,W]
+  float* ws;         // [nslab][9][CoP][CiP]
+  float* wsb;        // [nslab][CoP]
+  int N, Cin, Cout, CoP, CiP, H, W, P, R, VR, QZ, PX, Kext, nbands;
+  unsigned magic_h1;
+};
+
+template <int VW> struct Vec;
+template <> struct Vec<1> { using T = float; };
+template <> struct Vec<2> { using T = f32x2; };
+template <> struct Vec<4> { using T = f32x4; };
+template <int VW> __device__ __forceinline__ float vget(const typename Vec<VW>::T& v, int k) { return v[k]; }
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+template <int VW> __device__ __forceinline__ typename Vec<VW>::T vzero() { typename Vec<VW>::T z = {}; return z; }
+template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+
+__device__ __forceinline__ int fdiv(int v, unsigned magic) { return magic ? (int)__umulhi((unsigned)v, magic) : v; }
+
+// write VW consecutive elements (hi and lo) at element index e of a bf16 row
+template <int VW>
+__device__ __forceinline__ void put_split(__bf16* hi, __bf16* lo, int e, const typename Vec<VW>::T& v) {
+  __bf16 h[VW], l[VW];
+#pragma unroll
+  for (int k = 0; k < VW; ++k) {
+    const float f = vget<VW>(v, k);
+    h[k] = (__bf16)f;
+    l[k] = (__bf16)(f - (float)h[k]);
+  }
+  if constexpr (VW == 4) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<bf16x4*>(hi + e) = bf16x4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<bf16x4*>(lo + e) = bf16x4{l[0], l[1], l[2], l[3]};
+  } else if constexpr (VW == 2) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<bf16x2*>(hi + e) = bf16x2{h[0], h[1]};
+    *reinterpret_cast<bf16x2*>(lo + e) = bf16x2{l[0], l[1]};
+  } else {
+    hi[e] = h[0];
+    lo[e] = l[0];
+  }
+}
+
+// one-element funnel shift across two 16-byte chunks: out = elements [s .. s+8) of (lo_chunk | hi_chunk),
+// s = 1 (SH = 0) or s = 7 (SH = 1)
+template <int SH>
+__device__ __forceinline__ bf16x8 shift_chunks(const bf16x8& c_lo, const bf16x8& c_hi) {
+  const u32x4 a = __builtin_bit_cast(u32x4, c_lo), b = __builtin_bit_cast(u32x4, c_hi);
+  u32x4 o;
+  if (SH == 0) {            // elements 1..8: dwords (a0>>16|a1<<16), (a1|a2), (a2|a3), (a3|b0)
+    o[0] = __builtin_amdgcn_alignbyte(a[1], a[0], 2);
+    o[1] = __builtin_amdgcn_alignbyte(a[2], a[1], 2);
+    o[2] = __builtin_amdgcn_alignbyte(a[3], a[2], 2);
+    o[3] = __builtin_amdgcn_alignbyte(b[0], a[3], 2);
+  } else {                  // elements 7..14: dwords (a3>>16|b0<<16), (b0|b1), (b1|b2), (b2|b3)
+    o[0] = __builtin_amdgcn_alignbyte(b[0], a[3], 2);
+    o[1] = __builtin_amdgcn_alignbyte(b[1], b[0], 2);
+    o[2] = __builtin_amdgcn_alignbyte(b[2], b[1], 2);
+    o[3] = __builtin_amdgcn_alignbyte(b[3], b[2], 2);
+  }
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+// MTC co tiles per workgroup (64 or 32 output channels), 32 input channels per workgroup
+template <int MTC, int VW>
+__global__ void __launch_bounds__(NTHR, 1)
+k_wgrad3x3_x3(const WgX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MB = MTC * 32;
+  constexpr int KS = 4 / MTC;                         // K splits
+  constexpr int ZCH = MB / 16;                        // dz channel slots per thread (16 channels per pass)
+  constexpr int XCH = 2;
+  constexpr int RZ = zreg(VW) / (ZCH * VW);
+  constexpr int RX = xreg(VW) / (XCH * VW);
+  using VT = typename Vec<VW>::T;
+  __bf16* Zh = reinterpret_cast<__bf16*>(smem);       // [MB][QZ]
+  __bf16* Zl = Zh + MB * a.QZ;
+  __bf16* Xh = Zl + MB * a.QZ;                        // [32][PX]
+  __bf16* Xl = Xh + 32 * a.PX;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int cib = blockIdx.y, cob = blockIdx.z;
+  const int m = wid % MTC, kh = wid / MTC;
+  const int H1 = a.H + 1, P = a.P, W = a.W, R = a.R;
+  const int nks = a.Kext / 16;
+  const int ks0 = (nks * kh) / KS, ks1 = (nks * (kh + 1)) / KS;
+
+  {
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    const int n16 = (MB * a.QZ + 32 * a.PX) * 4 / 16;
+    for (int t = tid; t < n16; t += NTHR) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};   // pads stay zero
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const bf16x8* zrow_h = reinterpret_cast<const bf16x8*>(Zh + (m * 32 + l31) * a.QZ) + half;
+  const bf16x8* zrow_l = reinterpret_cast<const bf16x8*>(Zl + (m * 32 + l31) * a.QZ) + half;
+  const bf16x8* xrow_h = reinterpret_cast<const bf16x8*>(Xh + l31 * a.PX) + half;
+  const bf16x8* xrow_l = reinterpret_cast<const bf16x8*>(Xl + l31 * a.PX) + half;
+  const int p8 = P / 8;                               // row pitch in 16-byte chunks
+
+  // staging geometry: 16 lanes per row (W/VW <= 16), 16 channels per pass
+  const int wv = W / VW;
+  const int xv = tid & 15;
+  const int chl = tid >> 4;
+  const bool lane_ok = xv < wv;
+  const int co0 = cob * MB, ci0 = cib * 32;
+  const int HW = a.H * W;
+  float bpart[ZCH];
+#pragma unroll
+  for (int c = 0; c < ZCH; ++c) bpart[c] = 0.f;
+
+  VT pz[ZCH][RZ], px[XCH][RX];
+#define X3_WG_LOAD(V0)                                                                            \
+  {                                                                                               \
+    _Pragma("unroll") for (int r_ = 0; r_ < RZ; ++r_) {                                           \
+      const int v = (V0) + r_;                                                                    \
+      const int n = fdiv(v, a.magic_h1), yy = v - n * H1 - 1;                                     \
+      const bool rok = r_ < R && v < a.VR && yy >= 0;                                             \
+      const float* rowp = a.dz + ((size_t)n * a.Cout * a.H + yy) * W;                             \
+      _Pragma("unroll") for (int c_ = 0; c_ < ZCH; ++c_) {                                        \
+        const int ch = co0 + c_ * 16 + chl;                                                       \
+        pz[c_][r_] = (rok && lane_ok && ch < a.Cout)                                              \
+                         ? *reinterpret_cast<const VT*>(rowp + (size_t)ch * HW + xv * VW) : vzero<VW>(); \
+      }                                                                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int r_ = 0; r_ < RX; ++r_) {                                           \
+      const int v = (V0) - 1 + r_;                                                                \
+      const int n = fdiv(max(v, 0), a.magic_h1), yy = v - n * H1 - 1;                             \
+      const bool rok = r_ < R + 2 && v >= 0 && v < a.VR && yy >= 0;                               \
+      const float* rowp = a.x + ((size_t)n * a.Cin * a.H + yy) * W;                               \
+      _Pragma("unroll") for (int c_ = 0; c_ < XCH; ++c_) {                                        \
+        const int ch = ci0 + c_ * 16 + chl;                                                       \
+        px[c_][r_] = (rok && lane_ok && ch < a.Cin)                                               \
+                         ? *reinterpret_cast<const VT*>(rowp + (size_t)ch * HW + xv * VW) : vzero<VW>(); \
+      }                                                                                           \
+    }                                                                                             \
+  }
+#define X3_WG_STORE()                                                                             \
+  {                                                                                               \
+    if (lane_ok) {                                                                                \
+      _Pragma("unroll") for (int r_ = 0; r_ < RZ; ++r_) {                                         \
+        if (r_ < R) {                                                                             \
+          _Pragma("unroll") for (int c_ = 0; c_ < ZCH; ++c_) {                                    \
+            const int row_ = (c_ * 16 + chl) * a.QZ;                                              \
+            put_split<VW>(Zh + row_, Zl + row_, ZP + r_ * P + xv * VW, pz[c_][r_]);               \
+            _Pragma("unroll") for (int k_ = 0; k_ < VW; ++k_) bpart[c_] += vget<VW>(pz[c_][r_], k_); \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+      _Pragma("unroll") for (int r_ = 0; r_ < RX; ++r_) {                                         \
+        if (r_ < R + 2) {                                                                         \
+          _Pragma("unroll") for (int c_ = 0; c_ < XCH; ++c_) {                                    \
+            const int row_ = (c_ * 16 + chl) * a.PX;                                              \
+            put_split<VW>(Xh + row_, Xl + row_, XP + r_ * P + xv * VW, px[c_][r_]);               \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+    }                                                                                             \
+  }
+
+  int band = blockIdx.x;
+  if (band < a.nbands) X3_WG_LOAD(band * R)
+  for (; band < a.nbands; band += gridDim.x) {
+    __syncthreads();                 // previous band's MFMAs done (first pass: zero fill done)
+    X3_WG_STORE()
+    __syncthreads();
+    const int nb = band + gridDim.x;
+    if (nb < a.nbands) X3_WG_LOAD(nb * R)
+#pragma unroll 1
+    for (int ks = ks0; ks < ks1; ++ks) {
+      // dz chunks at elements e, e+8, e+16 (e = 16*ks + 8*half); kx=1 <- [e+8,e+16)
+      const bf16x8 z0h = zrow_h[2 * ks], z1h = zrow_h[2 * ks + 1], z2h = zrow_h[2 * ks + 2];
+      const bf16x8 z0l = zrow_l[2 * ks], z1l = zrow_l[2 * ks + 1], z2l = zrow_l[2 * ks + 2];
+      bf16x8 ah[3], al[3];
+      ah[1] = z1h; al[1] = z1l;
+      ah[0] = shift_chunks<0>(z1h, z2h); al[0] = shift_chunks<0>(z1l, z2l);     // elements e+9 ..
+      ah[2] = shift_chunks<1>(z0h, z1h); al[2] = shift_chunks<1>(z0l, z1l);     // elements e+7 ..
+      bf16x8 bh[3], bl[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) { bh[ky] = xrow_h[2 * ks + ky * p8]; bl[ky] = xrow_l[2 * ks + ky * p8]; }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int t = ky * 3 + kx;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kx], bl[ky], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kx], bh[ky], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kx], bh[ky], acc[t], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- combine K splits through LDS, one slab per workgroup; bias partials over the 16 column lanes
+  __syncthreads();
+  {
+    float* red = reinterpret_cast<float*>(smem);          // [MTC][144][64]
+#pragma unroll 1
+    for (int rnd = 1; rnd < KS; ++rnd) {
+      if (kh == rnd) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(m * 144 + t * 16 + r) * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (kh == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += red[(m * 144 + t * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+  }
+  const int s = blockIdx.x;
+  if (kh == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ci = ci0 + l31;
+        a.ws[(((size_t)s * 9 + t) * a.CoP + co) * a.CiP + ci] = acc[t][r];
+      }
+    }
+  }
+  if (cib == 0) {
+#pragma unroll
+    for (int c = 0; c < ZCH; ++c) {
+      float v = bpart[c];
+      v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+      if (xv == 0) a.wsb[(size_t)s * a.CoP + co0 + c * 16 + chl] = v;
+    }
+  }
+}
+
+// Fixed-order reduction of the slabs (same scheme as fdet_wgrad3x3.hip)
+__global__ void __launch_bounds__(1024)
+k_wgx3_reduce(const float* __restrict__ ws, const float* __restrict__ wsb, int nslab, int Cout, int Cin,
+              int CoP, int CiP, float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float part[1024];
+  const int tap = blockIdx.x;
+  const int e = threadIdx.x & 255, ph = threadIdx.x >> 8;
+  const int span = 4 * CiP;
+  const int co0 = blockIdx.y * 4;
+  for (int e0 = 0; e0 < span; e0 += 256) {
+    const int idx = e0 + e;
+    float s = 0.f;
+    if (idx < span && co0 + idx / CiP < CoP) {
+      const float* src = ws + ((size_t)tap * CoP + co0) * CiP + idx;
+#pragma unroll 4
+      for (int k = ph; k < nslab; k += 4) s += src[(size_t)k * 9 * CoP * CiP];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (ph == 0 && idx < span) {
+      const int co = co0 + idx / CiP, ci = idx % CiP;
+      if (co < Cout && ci < Cin)
+        dW[((size_t)co * Cin + ci) * 9 + tap] = ((part[e] + part[256 + e]) + part[512 + e]) + part[768 + e];
+    }
+    __syncthreads();
+  }
+  if (db && tap == 0 && threadIdx.x < 4 * 64) {
+    const int c = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    float s = 0.f;
+    if (co0 + c < Cout)
+      for (int k = ln; k < nslab; k += 64) s += wsb[(size_t)k * CoP + co0 + c];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (ln == 0 && co0 + c < Cout) db[co0 + c] = s;
+  }
+}
+
+unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
+struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw; size_t lds, ws_floats; bool ok; };
+
+WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W) {
+  WgX3Plan p{};
+  p.P = (W + 1 + 7) / 8 * 8;
+  p.VR = N * (H + 1) + 1;
+  p.CoP = (Cout + 31) / 32 * 32;
+  p.CiP = (Cin + 31) / 32 * 32;
+  p.MTC = (p.CoP % 64 == 0) ? 2 : 1;
+  p.vw = (W % 4 == 0) ? 4 : (W % 2 == 0 ? 2 : 1);
+  const int wv = W / p.vw;
+  p.ok = wv <= 16 && p.VR < (1 << 20) && (size_t)N * std::max(Cin, Cout) * H * W < ((size_t)1 << 31);
+  const int rows_total = p.VR - 1;
+  const int zch = p.MTC * 2;
+  const int rz = zreg(p.vw) / (zch * p.vw), rx = xreg(p.vw) / (2 * p.vw);
+  int bestR = 0; double bestC = 1e30;
+  for (int r = 1; r <= rz && r + 2 <= rx && r <= rows_total; ++r) {
+    const int Q = r * p.P;
+    const int Kext = (Q + 9 + 15) / 16 * 16;
+    int QZ = Kext + 24; if (((QZ / 8) & 1) == 0) QZ += 8;
+    int PX = Kext + 2 * p.P + 8; if (((PX / 8) & 1) == 0) PX += 8;
+    const size_t bytes = ((size_t)p.MTC * 32 * QZ + 32 * (size_t)PX) * 4;
+    if (bytes > 150 * 1024) break;
+    const long nb = (rows_total + r - 1) / r;
+    const long slots = 256 / ((p.CiP / 32) * (p.CoP / (p.MTC * 32)));   // workgroups along x so that the grid ~ 256
+    const long blk = std::max(1L, std::min(nb, slots));
+    const double mfma = (double)(((nb + blk - 1) / blk) * blk * Kext) / ((double)rows_total * p.P);
+    const double cost = mfma * (0.7 + 0.3 * (double)(r + 2) / r);
+    if (cost <= bestC * 1.0001) { bestC = cost; bestR = r; }
+  }
+  if (bestR == 0) { p.ok = false; bestR = 1; }
+  p.R = bestR;
+  const int Q = p.R * p.P;
+  p.Kext = (Q + 9 + 15) / 16 * 16;
+  p.QZ = p.Kext + 24; if (((p.QZ / 8) & 1) == 0) p.QZ += 8;
+  p.PX = p.Kext + 2 * p.P + 8; if (((p.PX / 8) & 1) == 0) p.PX += 8;
+  p.nbands = (rows_total + p.R - 1) / p.R;
+  const long slots = 256 / ((p.CiP / 32) * (p.CoP / (p.MTC * 32)));
+  p.nblk = (int)std::max(1L, std::min((long)p.nbands, slots));
+  p.lds = ((size_t)p.MTC * 32 * p.QZ + 32 * (size_t)p.PX) * 4;
+  p.lds = std::max(p.lds, (size_t)p.MTC * 144 * 64 * 4);
+  p.ws_floats = (size_t)p.nblk * 9 * p.CoP * p.CiP + (size_t)p.nblk * p.CoP;
+  return p;
+}
+
+template <int MTC>
+void launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) {
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds, st, a);
+  };
+  if (p.vw == 4) go(k_wgrad3x3_x3<MTC, 4>);
+  else if (p.vw == 2) go(k_wgrad3x3_x3<MTC, 2>);
+  else go(k_wgrad3x3_x3<MTC, 1>);
+}
+
+}  // namespace
+
+extern "C" size_t fdet_conv3x3_wgrad_bf16x3_ws_bytes(int N, int Cin, int Cout, int H, int W) {
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  const WgX3Plan p = plan_x3(N, Cin, Cout, H, W);
+  return p.ok ? p.ws_floats * 4 : 0;
+}
+
+extern "C" int fdet_conv3x3_wgrad_bf16x3(const float* x, const float* dz, float* dW, float* db, void* ws,
+                                         size_t ws_bytes, int N, int Cin, int Cout, int H, int W, void* stream) {
+  FDET_REQUIRE(x && dz && dW && ws, "conv3x3_wgrad_bf16x3: null pointer");
+  FDET_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_wgrad_bf16x3: bad shape");
+  const WgX3Plan p = plan_x3(N, Cin, Cout, H, W);
+  FDET_REQUIRE(p.ok, "conv3x3_wgrad_bf16x3: no tiling for N=%d H=%d W=%d (row must fit 16 vector lanes)", N, H, W);
+  if (ws_bytes < p.ws_floats * 4)
+    return fail(FDET_EWORKSPACE, "conv3x3_wgrad_bf16x3: workspace %zu < %zu bytes", ws_bytes, p.ws_floats * 4);
+  WgX3Args a;
+  a.x = x; a.dz = dz; a.ws = (float*)ws; a.wsb = (float*)ws + (size_t)p.nblk * 9 * p.CoP * p.CiP;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.CoP = p.CoP; a.CiP = p.CiP; a.H = H; a.W = W; a.P = p.P; a.R = p.R;
+  a.VR = p.VR; a.QZ = p.QZ; a.PX = p.PX; a.Kext = p.Kext; a.nbands = p.nbands; a.magic_h1 = magic_of(H + 1);
+  dim3 grid(p.nblk, p.CiP / 32, p.CoP / (p.MTC * 32));
+  hipStream_t st = (hipStream_t)stream;
+  if (p.MTC == 2) launch_x3<2>(a, p, grid, st); else launch_x3<1>(a, p, grid, st);
+  if (int rc = check_launch("fdet_conv3x3_wgrad_bf16x3")) return rc;
+  hipLaunchKernelGGL(k_wgx3_reduce, dim3(9, (Cout + 3) / 4), dim3(1024), 0, st, a.ws, a.wsb, p.nblk, Cout, Cin, p.CoP,
+                     p.CiP, dW, db);
+  return check_launch("fdet_conv3x3_wgrad_bf16x3(reduce)");
+}

@@ -217,17 +217,24 @@ def conv3x3_dgrad(dz, wpk_bwd, cin: int, dx, act=None, add=None, slope: float = 
 
 
 def conv3x3_wgrad_ws_bytes(Nn, cin, cout, H, W) -> int:
-    return int(lib().fdet_conv3x3_wgrad_ws_bytes(Nn, cin, cout, H, W))
+    """Workspace that serves BOTH precisions of conv3x3_wgrad."""
+    return max(int(lib().fdet_conv3x3_wgrad_ws_bytes(Nn, cin, cout, H, W)),
+               int(lib().fdet_conv3x3_wgrad_bf16x3_ws_bytes(Nn, cin, cout, H, W)))
 
 
-def conv3x3_wgrad(x, dz, dW, db, ws):
+def wgrad_x3_supported(Nn, cin, cout, H, W) -> bool:
+    return int(lib().fdet_conv3x3_wgrad_bf16x3_ws_bytes(Nn, cin, cout, H, W)) > 0
+
+
+def conv3x3_wgrad(x, dz, dW, db, ws, x3: bool = False):
     Nn, cin, H, W = x.shape
     cout = dz.shape[1]
     _chk4(dz, (Nn, cout, H, W), "dz")
     _chk4(dW, (cout, cin, 3, 3), "dW")
     _chk4(db, (cout,), "db")
-    check(lib().fdet_conv3x3_wgrad(ptr(x), ptr(dz), ptr(dW), ptr(db), ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
-                                   Nn, cin, cout, H, W, stream()), "fdet_conv3x3_wgrad")
+    fn = lib().fdet_conv3x3_wgrad_bf16x3 if x3 else lib().fdet_conv3x3_wgrad
+    check(fn(ptr(x), ptr(dz), ptr(dW), ptr(db), ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
+             Nn, cin, cout, H, W, stream()), "fdet_conv3x3_wgrad")
 
 
 def block_tail_fwd(c, x, drop_scale, out, pool: int):

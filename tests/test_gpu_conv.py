@@ -73,7 +73,7 @@ def test_conv3x3_fwd_dgrad_wgrad(hp, shape, x3):
     # weight gradient
     ws = torch.empty(hp.conv3x3_wgrad_ws_bytes(N, C, C, H, W) // 4, device="cuda")
     dW = torch.full((C, C, 3, 3), float("nan"), device="cuda"); db = torch.full((C,), float("nan"), device="cuda")
-    hp.conv3x3_wgrad(xd, dz.cuda(), dW, db, ws)
+    hp.conv3x3_wgrad(xd, dz.cuda(), dW, db, ws, x3=x3 and hp.wgrad_x3_supported(N, C, C, H, W))
     xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     F.conv2d(xr, wr, br, padding=1).backward(dz)
     close(dW, wr.grad)

@@ -51,6 +51,6 @@ for H in (60, 30, 15):
     t1b = timeit(lambda: hp.conv3x3_fwd(x, wf, b, C, y_full=y, skip=x, drop_scale=sc, y_out=y2, x3=bool(args.x3)))
     t2 = timeit(lambda: hp.conv3x3_dgrad(dz, wb, C, y, act=x, x3=bool(args.x3)))
     t2b = timeit(lambda: hp.conv3x3_dgrad(dz, wb, C, y, add=x, x3=bool(args.x3)))
-    t3 = timeit(lambda: hp.conv3x3_wgrad(x, dz, dW, db, ws))
+    t3 = timeit(lambda: hp.conv3x3_wgrad(x, dz, dW, db, ws, x3=bool(args.x3)))
     print(f"{H}x{H}: fwd {t1:.3f} ms ({fl/t1/1e9:.1f} TF) | fwd+tail {t1b:.3f} ({fl/t1b/1e9:.1f}) | dgrad+act {t2:.3f} ({fl/t2/1e9:.1f}) | "
           f"dgrad+add {t2b:.3f} ({fl/t2b/1e9:.1f}) | wgrad {t3:.3f} ({fl/t3/1e9:.1f} TF)   ideal@157TF {fl/157.3e9:.3f} ms")
