@@ -77,7 +77,7 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for name, (evs, flops, nbytes) in self.rec.items():
-            out[name] = (len(evs), sum(a.elapsed_time(b) for a, b in evs), flops, nbytes)
+            out[name] = (len(evs), sum(a.elapsed_time(b) for a, b in evs), flops / len(evs), nbytes / len(evs))
         return out
 
 
@@ -92,7 +92,10 @@ class _Span:
 
     def __exit__(self, *exc):
         self.b.record()
-        self.t.rec.setdefault(self.name, [[], self.flops, self.nbytes])[0].append((self.a, self.b))
+        rec = self.t.rec.setdefault(self.name, [[], 0.0, 0.0])
+        rec[0].append((self.a, self.b))
+        rec[1] += self.flops
+        rec[2] += self.nbytes
 
 
 class _NoSpan:
@@ -133,6 +136,11 @@ class ConvStack:
     def _conv_flops(self, N: int, h: int) -> float:
         F_ = self.geo.filters
         return 2.0 * N * F_ * F_ * 9 * h * h
+
+    def _act_bytes(self, N: int, h: int, tensors: int) -> float:
+        """Algorithmic HBM bytes of `tensors` activation-sized fp32 tensors (SURVEY.md 8d:
+        every input read once, every output written once; weights are L2-resident)."""
+        return 4.0 * N * self.geo.filters * h * h * tensors
 
     # ------------------------------------------------------------------ weights
     def _ensure_packed(self, P: Dict[str, torch.Tensor], force: bool = False):
@@ -186,18 +194,18 @@ class ConvStack:
             name = f"residual_blocks.{k}"
             sc = masks[name] if masks is not None else None
             a = torch.empty(N, F_, hk, hk, dtype=F32, device=dev)
-            with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk)):
+            with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2)):
                 hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], F_, y_full=a, slope=self.slope, x3=self.x3)
             out = torch.empty(N, F_, hk // pool, hk // pool, dtype=F32, device=dev)
             if pool == 2:
                 c = torch.empty_like(a)
-                with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk)):
+                with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2)):
                     hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, slope=self.slope, x3=self.x3)
                 with self._t("tail_fwd", N, hk):
                     hp.block_tail_fwd(c, h, sc, out, 2)
             else:
                 c = torch.empty_like(a) if save else None
-                with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk)):
+                with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 4 if save else 3)):
                     hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, skip=h,
                                    drop_scale=sc, y_out=out, slope=self.slope, x3=self.x3)
             if save:
@@ -245,15 +253,15 @@ class ConvStack:
             fl = self._conv_flops(N, hk)
             wws = self._workspace("wgrad", hp.conv3x3_wgrad_ws_bytes(N, F_, F_, hk, hk), dev)
             wx3 = self.x3 and hp.wgrad_x3_supported(N, F_, F_, hk, hk)
-            with self._t("conv3x3_wgrad", N, hk, fl):
+            with self._t("conv3x3_wgrad", N, hk, fl, self._act_bytes(N, hk, 2)):
                 hp.conv3x3_wgrad(a, dz2, G[name + ".conv2.weight"], G[name + ".conv2.bias"], wws, x3=wx3)
             dz1 = torch.empty_like(a)
-            with self._t("conv3x3_dgrad", N, hk, fl):
+            with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
                 hp.conv3x3_dgrad(dz2, self._wpk[name + ".conv2.b"], F_, dz1, act=a, slope=self.slope, x3=self.x3)
-            with self._t("conv3x3_wgrad", N, hk, fl):
+            with self._t("conv3x3_wgrad", N, hk, fl, self._act_bytes(N, hk, 2)):
                 hp.conv3x3_wgrad(xin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], wws, x3=wx3)
             dx = dz2                                   # reuse: dz2 is dead after its wgrad/dgrad
-            with self._t("conv3x3_dgrad", N, hk, fl):
+            with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
                 hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], F_, dx, add=de, slope=self.slope, x3=self.x3)
             dout = dx
             if after_block is not None:
