@@ -201,10 +201,17 @@ int fdet_block_tail_bwd(const float* dout, const float* c, const float* x, const
 size_t fdet_stem_ws_bytes(int N, int Cin, int F, int H, int W, int k, int stride, int pad);
 int fdet_stem_fwd(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
                   int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream);
+/* bf16x3 variant of fdet_stem_fwd (PoolResnet geometry only: 3 channels, k10 s8 p2); same
+ * arguments, results within ~1e-5.  `ws` is unused. */
+int fdet_stem_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                         int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream);
 /* dW [F,Cin,k,k], db [F] from x and dy [N,F,Ho,Wo] (autograd of the stem; the input image
  * needs no gradient, so there is no data-gradient entry point). */
 int fdet_stem_wgrad(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,
                     int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream);
+/* bf16x3 variant of fdet_stem_wgrad (PoolResnet geometry, W % 16 == 0); same workspace size. */
+int fdet_stem_wgrad_bf16x3(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,
+                           int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream);
 
 /* Head: Dropout2d(0.5) + Conv2d(F,5,k,pad) + Sigmoid.  Replaces models/PoolResnet.py:100-102
  * (k6 p0) and models/Resnet.py:94-96 (k3 p1).

@@ -65,7 +65,9 @@ SIGNATURES = {
     "fdet_block_tail_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_stem_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "fdet_stem_fwd": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fdet_stem_fwd_bf16x3": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_stem_wgrad": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fdet_stem_wgrad_bf16x3": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_head_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_head_bwd_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "fdet_head_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _P]),

@@ -188,7 +188,8 @@ class ConvStack:
         h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev)
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
         with self._t("stem_fwd", N, self.h0, stem_flops):
-            hp.stem_fwd(x, P["conv1.weight"], P["conv1.bias"], h, ws, g.stem_k, g.stem_s, g.stem_p)
+            hp.stem_fwd(x, P["conv1.weight"], P["conv1.bias"], h, ws, g.stem_k, g.stem_s, g.stem_p,
+                        x3=self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p))
         saved = {"x": x, "blocks": [], "masks": masks} if save else None
         for k, (hk, pool) in enumerate(self.lv):
             name = f"residual_blocks.{k}"
@@ -269,7 +270,8 @@ class ConvStack:
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
         with self._t("stem_wgrad", N, self.h0, stem_flops):
-            hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p)
+            hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p,
+                          x3=self.x3 and g.W % 16 == 0 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p))
 
 
 def param_names(num_blocks: int) -> List[str]:

@@ -17,6 +17,8 @@ bool stem_mfma_ok(int Cin, int F, int H, int W, int k, int stride, int pad);
 size_t stem_mfma_ws_floats(int N, int F, int H, int W);
 int stem_mfma_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W, hipStream_t st);
 int stem_mfma_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st);
+int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W, hipStream_t st);   // fdet_stem_x3.hip
+int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st);
 }
 
 namespace {
@@ -226,6 +228,26 @@ extern "C" int fdet_stem_fwd(const float* x, const float* w, const float* bias, 
     hipLaunchKernelGGL((k_stem_fwd<3, 2, 1, 3>), grid, dim3(256), p.lds_fwd, st, x, wpk, bias, y, F, p.FP, H, W, p.Ho, p.Wo, p.BXS);
   }
   return check_launch("fdet_stem_fwd");
+}
+
+extern "C" int fdet_stem_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes,
+                                    int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream) {
+  (void)ws; (void)ws_bytes;
+  FDET_REQUIRE(x && w && bias && y && N > 0 && F > 0, "stem_fwd_bf16x3: bad arguments");
+  FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad),
+               "stem_fwd_bf16x3: only the PoolResnet stem (3ch k10 s8 p2, W%%4==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
+               Cin, k, stride, pad, W);
+  return stem_x3_fwd(x, w, bias, y, N, F, H, W, (hipStream_t)stream);
+}
+
+extern "C" int fdet_stem_wgrad_bf16x3(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,
+                                      int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream) {
+  FDET_REQUIRE(x && dy && dW && db && ws && N > 0 && F > 0, "stem_wgrad_bf16x3: bad arguments");
+  FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad) && W % 16 == 0,
+               "stem_wgrad_bf16x3: only the PoolResnet stem (3ch k10 s8 p2, W%%16==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
+               Cin, k, stride, pad, W);
+  if (ws_bytes < stem_mfma_ws_floats(N, F, H, W) * 4) return fail(FDET_EWORKSPACE, "stem_wgrad_bf16x3: workspace too small");
+  return stem_x3_wgrad(x, dy, dW, db, (float*)ws, N, F, H, W, (hipStream_t)stream);
 }
 
 extern "C" int fdet_stem_wgrad(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,

@@ -1,0 +1,374 @@
+// PoolResnet stem (Conv2d(3,F,10,stride 8,pad 2)) in bf16x3 arithmetic (x = hi + lo bf16 split,
+// three MFMA passes, fp32 accumulation): forward.
+//
+// One band = one output row (n, oy).  MFMA K = one (ci, ky) input row segment of 16 taps:
+//   t = kx + 2 in [0,16)  (taps outside [2,12) carry zero weights)
+// so a lane's B fragment for output column ox and k-half h is the 8 consecutive input pixels
+// 8*ox + 8*h + j - 4 ... stored row-major with a 4-element zero pad: LDS index 8*ox + 8*h + j --
+// one aligned 16-byte read, consecutive lanes -> consecutive chunks (no de-interleave needed, the
+// stride-8 of the conv turns into the natural 8-element fragment granularity).
+// Weights live in registers for the whole kernel (30 rows x (hi,lo) x 4 VGPRs = 240 per lane).
+#include "fdet_common.h"
+
+using namespace fdet;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KS = 10, ST = 8, PD = 2, CIN = 3;
+constexpr int NROW = CIN * KS;             // 30 (ci, ky) rows = MFMA K steps
+constexpr int RL = 8 * 64 + 16;            // row length in elements (chunks: 66)
+constexpr int RC = RL / 8;
+constexpr int NSLOT = 15;                  // float4 staging slots per thread: 30 rows x 128 lanes / 256
+
+struct StemX3Args {
+  const float* x; const float* w; const float* bias; float* y;
+  int N, F, H, W, Ho, Wo, nrows;
+};
+
+__global__ void __launch_bounds__(256, 1)
+k_stem_fwd_x3(const StemX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* Xh = reinterpret_cast<__bf16*>(smem);         // [30][RL]
+  __bf16* Xl = Xh + NROW * RL;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int m = wid & 1, nt = wid >> 1;
+  const int cob = blockIdx.y;
+  const int co = cob * 64 + m * 32 + l31;
+  const int jmax = a.W / 4;
+
+  {
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    for (int t = tid; t < NROW * RL * 4 / 16; t += 256) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // A fragments: row rr = ci*10 + ky, element j <-> tap t = 8*half + j, kx = t - 2
+  bf16x8 ah[NROW], al[NROW];
+#pragma unroll
+  for (int rr = 0; rr < NROW; ++rr) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kx = 8 * half + j - 2;
+      const float f = (co < a.F && kx >= 0 && kx < KS) ? a.w[((size_t)co * CIN * KS + rr) * KS + kx] : 0.f;
+      const __bf16 h = (__bf16)f;
+      ah[rr][j] = h;
+      al[rr][j] = (__bf16)(f - (float)h);
+    }
+  }
+  const bf16x8* Bh = reinterpret_cast<const bf16x8*>(Xh) + nt * 32 + l31 + half;
+  const bf16x8* Bl = reinterpret_cast<const bf16x8*>(Xl) + nt * 32 + l31 + half;
+
+  f32x4 px[NSLOT];
+#define SX3_LOAD(ROW_N, ROW_OY)                                                                 \
+  {                                                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < NSLOT; ++s_) {                                      \
+      const int it = s_ * 256 + tid;                                                            \
+      const int rr = it >> 7, j = it & 127;                                                     \
+      const int ci = rr / KS, ky = rr - ci * KS;                                                \
+      const int iy = (ROW_OY) * ST - PD + ky;                                                   \
+      const bool ok = j < jmax && iy >= 0 && iy < a.H;                                          \
+      px[s_] = ok ? *reinterpret_cast<const f32x4*>(a.x + (((size_t)(ROW_N) * CIN + ci) * a.H + iy) * a.W + j * 4) \
+                  : f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+    }                                                                                           \
+  }
+#define SX3_STORE()                                                                             \
+  {                                                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < NSLOT; ++s_) {                                      \
+      const int it = s_ * 256 + tid;                                                            \
+      const int rr = it >> 7, j = it & 127;                                                     \
+      if (j < jmax) {                                                                           \
+        bf16x4 h4, l4;                                                                          \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                      \
+          const __bf16 h = (__bf16)px[s_][c_];                                                  \
+          h4[c_] = h; l4[c_] = (__bf16)(px[s_][c_] - (float)h);                                 \
+        }                                                                                       \
+        *reinterpret_cast<bf16x4*>(Xh + rr * RL + 4 + 4 * j) = h4;                              \
+        *reinterpret_cast<bf16x4*>(Xl + rr * RL + 4 + 4 * j) = l4;                              \
+      }                                                                                         \
+    }                                                                                           \
+  }
+
+  int row = blockIdx.x;
+  if (row < a.nrows) { const int n = row / a.Ho, oy = row - n * a.Ho; SX3_LOAD(n, oy) }
+  for (; row < a.nrows; row += gridDim.x) {
+    const int n = row / a.Ho, oy = row - n * a.Ho;
+    __syncthreads();
+    SX3_STORE()
+    __syncthreads();
+    const int nrow = row + gridDim.x;
+    if (nrow < a.nrows) { const int n2 = nrow / a.Ho, oy2 = nrow - n2 * a.Ho; SX3_LOAD(n2, oy2) }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    bf16x8 bh[2], bl[2];
+    bh[0] = Bh[0]; bl[0] = Bl[0];
+#pragma unroll
+    for (int rr = 0; rr < NROW; ++rr) {
+      const int cur = rr & 1, nxt = cur ^ 1;
+      if (rr + 1 < NROW) { bh[nxt] = Bh[(rr + 1) * RC]; bl[nxt] = Bl[(rr + 1) * RC]; }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bl[cur], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bh[cur], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bh[cur], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int ox = nt * 32 + l31;
+    if (ox < a.Wo) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c2 = cob * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (c2 < a.F) a.y[(((size_t)n * a.F + c2) * a.Ho + oy) * a.Wo + ox] = acc[r] + a.bias[c2];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient, bf16x3:  dW[co][ci,ky,kx] = sum_ox dy[co][ox] * x[ci][8oy+ky-2][8ox+kx-2]
+// MFMA K = 16 output columns.  B needs 8 consecutive ox for one tap = a stride-8 walk over the
+// input row, so the row is staged DE-INTERLEAVED by column phase: plane (row, ix % 8), element
+// ix / 8 (+8 zero front pad).  Taps kx = 2..9 read phase kx-2 at element ox (aligned chunk);
+// taps kx = 0,1 read phase 6,7 at element ox-1 (one-element funnel shift of two chunks).
+// N tiles: 0..7 hold the 240 aligned taps (row*8 + kx-2), 8..9 the 60 shifted ones (row*2 + kx).
+// ---------------------------------------------------------------------------------------
+constexpr int PC = 11;                     // chunks per plane (88 elements: 8 pad + 61 + slack), odd
+constexpr int PE = PC * 8;
+constexpr int NPLANE = NROW * 8;           // 240
+constexpr int DL = 72;                     // dy row length (elements), DL/8 odd
+constexpr int WSLOT = 4;                   // staging slots: 30 rows x 30 groups of 16 pixels / 256 threads
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct StemWgX3Args {
+  const float* x; const float* dy; float* ws; float* wsb;
+  int N, F, H, W, Ho, Wo, nrows;
+};
+
+__device__ __forceinline__ bf16x8 shift7(const bf16x8& c0, const bf16x8& c1) {      // elements 7..14 of (c0|c1)
+  const u32x4 a = __builtin_bit_cast(u32x4, c0), b = __builtin_bit_cast(u32x4, c1);
+  u32x4 o;
+  o[0] = __builtin_amdgcn_alignbyte(b[0], a[3], 2);
+  o[1] = __builtin_amdgcn_alignbyte(b[1], b[0], 2);
+  o[2] = __builtin_amdgcn_alignbyte(b[2], b[1], 2);
+  o[3] = __builtin_amdgcn_alignbyte(b[3], b[2], 2);
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_stem_wgrad_x3(const StemWgX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* Ph = reinterpret_cast<__bf16*>(smem);         // [240 planes][PE]
+  __bf16* Pl = Ph + NPLANE * PE;
+  __bf16* Dh = Pl + NPLANE * PE;                        // [64 co][DL]
+  __bf16* Dl = Dh + 64 * DL;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int m = wid & 1, ng = wid >> 1;                 // co tile, N-tile group (tiles 5*ng .. 5*ng+4)
+  const int cob = blockIdx.y;
+  const int gmax = a.W / 16, dmax = a.Wo / 4;
+
+  {
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    for (int t = tid; t < (NPLANE * PE + 64 * DL) * 4 / 16; t += 256) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // per-lane chunk base of each of this wave's 5 N tiles
+  int pbase[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int tile = ng * 5 + t;
+    int plane, extra;
+    if (tile < 8) {                                     // aligned taps: kk = row*8 + (kx-2)
+      const int kk = min(tile * 32 + l31, NROW * 8 - 1);
+      plane = kk; extra = 1;                            // +1 chunk: the 8-element front pad
+    } else {                                            // shifted taps: kk2 = row*2 + kx, phase 6 + kx
+      const int kk2 = min((tile - 8) * 32 + l31, NROW * 2 - 1);
+      plane = (kk2 >> 1) * 8 + 6 + (kk2 & 1); extra = 0;
+    }
+    pbase[t] = plane * PC + extra + half;
+  }
+  const bf16x8* Bh = reinterpret_cast<const bf16x8*>(Ph);
+  const bf16x8* Bl = reinterpret_cast<const bf16x8*>(Pl);
+  const bf16x8* Ah = reinterpret_cast<const bf16x8*>(Dh + (m * 32 + l31) * DL) + half;
+  const bf16x8* Al = reinterpret_cast<const bf16x8*>(Dl + (m * 32 + l31) * DL) + half;
+
+  f32x16 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bpart[4] = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 px[WSLOT][4], pd[4];
+#define SWX3_LOAD(ROW_N, ROW_OY)                                                                \
+  {                                                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < WSLOT; ++s_) {                                      \
+      const int it = s_ * 256 + tid;                                                            \
+      const int rr = it >> 5, g_ = it & 31;                                                     \
+      const int rc = min(rr, NROW - 1);                                                         \
+      const int ci = rc / KS, ky = rc - ci * KS;                                                \
+      const int iy = (ROW_OY) * ST - PD + ky;                                                   \
+      const bool ok = rr < NROW && g_ < gmax && iy >= 0 && iy < a.H;                            \
+      const float* src = a.x + (((size_t)(ROW_N) * CIN + ci) * a.H + max(iy, 0)) * a.W + g_ * 16; \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                          \
+        px[s_][q_] = ok ? *reinterpret_cast<const f32x4*>(src + q_ * 4) : f32x4{0.f, 0.f, 0.f, 0.f}; \
+    }                                                                                           \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                          \
+      const int it = s_ * 256 + tid;                                                            \
+      const int c = it >> 4, j = it & 15;                                                       \
+      const int cg = cob * 64 + c;                                                              \
+      pd[s_] = (j < dmax && cg < a.F)                                                           \
+                   ? *reinterpret_cast<const f32x4*>(a.dy + (((size_t)(ROW_N) * a.F + cg) * a.Ho + (ROW_OY)) * a.Wo + j * 4) \
+                   : f32x4{0.f, 0.f, 0.f, 0.f};                                                 \
+    }                                                                                           \
+  }
+  // pixel ix = 16g + i  ->  plane row*8 + (i & 7), element 8 + 2g + (i >> 3): (i, i+8) pack into one dword
+#define SWX3_STORE()                                                                            \
+  {                                                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < WSLOT; ++s_) {                                      \
+      const int it = s_ * 256 + tid;                                                            \
+      const int rr = it >> 5, g_ = it & 31;                                                     \
+      if (rr < NROW && g_ < gmax) {                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                      \
+          const float f0 = px[s_][i_ >> 2][i_ & 3], f1 = px[s_][2 + (i_ >> 2)][i_ & 3];        \
+          const __bf16 h0 = (__bf16)f0, h1 = (__bf16)f1;                                        \
+          const int e_ = (rr * 8 + i_) * PE + 8 + 2 * g_;                                       \
+          *reinterpret_cast<bf16x2*>(Ph + e_) = bf16x2{h0, h1};                                 \
+          *reinterpret_cast<bf16x2*>(Pl + e_) = bf16x2{(__bf16)(f0 - (float)h0), (__bf16)(f1 - (float)h1)}; \
+        }                                                                                       \
+      }                                                                                         \
+    }                                                                                           \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                          \
+      const int it = s_ * 256 + tid;                                                            \
+      const int c = it >> 4, j = it & 15;                                                       \
+      if (j < dmax) {                                                                           \
+        bf16x4 h4, l4;                                                                          \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                      \
+          const __bf16 h = (__bf16)pd[s_][c_];                                                  \
+          h4[c_] = h; l4[c_] = (__bf16)(pd[s_][c_] - (float)h);                                 \
+          bpart[s_] += pd[s_][c_];                                                              \
+        }                                                                                       \
+        *reinterpret_cast<bf16x4*>(Dh + c * DL + 4 * j) = h4;                                   \
+        *reinterpret_cast<bf16x4*>(Dl + c * DL + 4 * j) = l4;                                   \
+      }                                                                                         \
+    }                                                                                           \
+  }
+
+  int row = blockIdx.x;
+  if (row < a.nrows) { const int n = row / a.Ho, oy = row - n * a.Ho; SWX3_LOAD(n, oy) }
+  const int nks = (a.Wo + 15) / 16;
+  for (; row < a.nrows; row += gridDim.x) {
+    __syncthreads();
+    SWX3_STORE()
+    __syncthreads();
+    const int nrow = row + gridDim.x;
+    if (nrow < a.nrows) { const int n2 = nrow / a.Ho, oy2 = nrow - n2 * a.Ho; SWX3_LOAD(n2, oy2) }
+#pragma unroll 1
+    for (int ks = 0; ks < nks; ++ks) {
+      const bf16x8 ah = Ah[2 * ks], al = Al[2 * ks];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        bf16x8 bh, bl;
+        if (ng * 5 + t < 8) {
+          bh = Bh[pbase[t] + 2 * ks]; bl = Bl[pbase[t] + 2 * ks];
+        } else {
+          bh = shift7(Bh[pbase[t] + 2 * ks], Bh[pbase[t] + 2 * ks + 1]);
+          bl = shift7(Bl[pbase[t] + 2 * ks], Bl[pbase[t] + 2 * ks + 1]);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // slab ws[blk][co][320]: column k' = tile*32 + lane (decoded by the reduce kernel)
+  const int FP = gridDim.y * 64;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int kp = (ng * 5 + t) * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c2 = cob * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      a.ws[((size_t)blockIdx.x * FP + c2) * 320 + kp] = acc[t][r];
+    }
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    float v = bpart[s_];
+    v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+    const int c = (s_ * 256 + tid) >> 4;
+    if ((tid & 15) == 0) a.wsb[(size_t)blockIdx.x * FP + cob * 64 + c] = v;
+  }
+}
+
+// dW[f][ci,ky,kx] = sum_b ws[b][f][k'] with k' -> tap decode; db[f] = sum_b wsb[b][f]  (fixed order)
+__global__ void __launch_bounds__(256)
+k_stem_x3_reduce(const float* __restrict__ ws, const float* __restrict__ wsb, int nblk, int F, int FP,
+                 float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float part[256];
+  const int f = blockIdx.y;
+  const int kq = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int kp = blockIdx.x * 64 + kq;
+  float s = 0.f;
+  if (kp < 320)
+    for (int b = ph; b < nblk; b += 4) s += ws[((size_t)b * FP + f) * 320 + kp];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (ph == 0 && kp < 320) {
+    int rr = -1, kx = 0;
+    if (kp < 256) { if (kp < NROW * 8) { rr = kp >> 3; kx = (kp & 7) + 2; } }
+    else { const int k2 = kp - 256; if (k2 < NROW * 2) { rr = k2 >> 1; kx = k2 & 1; } }
+    if (rr >= 0) dW[((size_t)f * NROW + rr) * KS + kx] = ((part[kq] + part[64 + kq]) + part[128 + kq]) + part[192 + kq];
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    float t = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) t += wsb[(size_t)b * FP + f];
+    part[threadIdx.x] = t;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) db[f] = part[0];
+  }
+}
+
+}  // namespace
+
+namespace fdet {
+
+int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W,
+                hipStream_t st) {
+  StemX3Args a{};
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.N = N; a.F = F; a.H = H; a.W = W;
+  a.Ho = (H + 4 - 10) / 8 + 1; a.Wo = (W + 4 - 10) / 8 + 1; a.nrows = N * a.Ho;
+  const int FP = (F + 63) / 64 * 64;
+  const int nblk = a.nrows < 256 ? a.nrows : 256;
+  const size_t lds = (size_t)NROW * RL * 2 * 2;
+  (void)hipFuncSetAttribute((const void*)k_stem_fwd_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_stem_fwd_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
+  return check_launch("fdet_stem_fwd(bf16x3)");
+}
+
+int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W,
+                  hipStream_t st) {
+  StemWgX3Args a{};
+  a.x = x; a.dy = dy; a.N = N; a.F = F; a.H = H; a.W = W;
+  a.Ho = (H + 4 - 10) / 8 + 1; a.Wo = (W + 4 - 10) / 8 + 1; a.nrows = N * a.Ho;
+  const int FP = (F + 63) / 64 * 64;
+  const int nblk = a.nrows < 256 ? a.nrows : 256;
+  a.ws = ws; a.wsb = ws + (size_t)nblk * FP * 320;
+  const size_t lds = ((size_t)NPLANE * PE * 2 + 64 * DL * 2) * 2;
+  (void)hipFuncSetAttribute((const void*)k_stem_wgrad_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_stem_wgrad_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
+  if (int rc = check_launch("fdet_stem_wgrad(bf16x3)")) return rc;
+  hipLaunchKernelGGL(k_stem_x3_reduce, dim3(5, F), dim3(256), 0, st, a.ws, a.wsb, nblk, F, FP, dW, db);
+  return check_launch("fdet_stem_wgrad(bf16x3 reduce)");
+}
+
+}  // namespace fdet

@@ -264,24 +264,30 @@ def stem_ws_bytes(Nn, cin, F_, H, W, k, stride, pad) -> int:
     return int(lib().fdet_stem_ws_bytes(Nn, cin, F_, H, W, k, stride, pad))
 
 
-def stem_fwd(x, w, bias, y, ws, k, stride, pad):
+def stem_x3_supported(cin, W, k, stride, pad) -> bool:
+    return cin == 3 and (k, stride, pad) == (10, 8, 2) and W % 4 == 0 and W <= 512 and ((W + 2 * pad - k) // stride + 1) % 4 == 0
+
+
+def stem_fwd(x, w, bias, y, ws, k, stride, pad, x3: bool = False):
     Nn, cin, H, W = x.shape
     F_ = w.shape[0]
     _chk4(w, (F_, cin, k, k), "w")
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     _chk4(y, (Nn, F_, Ho, Wo), "y")
-    check(lib().fdet_stem_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
-                              Nn, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_fwd")
+    fn = lib().fdet_stem_fwd_bf16x3 if x3 else lib().fdet_stem_fwd
+    check(fn(ptr(x), ptr(w), ptr(bias), ptr(y), ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
+             Nn, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_fwd")
 
 
-def stem_wgrad(x, dy, dW, db, ws, k, stride, pad):
+def stem_wgrad(x, dy, dW, db, ws, k, stride, pad, x3: bool = False):
     Nn, cin, H, W = x.shape
     F_ = dW.shape[0]
     _chk4(dW, (F_, cin, k, k), "dW")
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     _chk4(dy, (Nn, F_, Ho, Wo), "dy")
-    check(lib().fdet_stem_wgrad(ptr(x), ptr(dy), ptr(dW), ptr(db), ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
-                                Nn, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_wgrad")
+    fn = lib().fdet_stem_wgrad_bf16x3 if x3 else lib().fdet_stem_wgrad
+    check(fn(ptr(x), ptr(dy), ptr(dW), ptr(db), ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
+             Nn, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_wgrad")
 
 
 def head_fwd(x, drop_scale, w, bias, y, k, pad):

@@ -120,6 +120,10 @@ def test_stem(hp, cfg):
     y = torch.full((N, Fo, Ho, Ho), float("nan"), device="cuda")
     hp.stem_fwd(x.cuda(), w.cuda(), b.cuda(), y, ws, k, s, p)
     close(y, F.conv2d(x, w, b, stride=s, padding=p))
+    if hp.stem_x3_supported(3, size, k, s, p):                  # bf16x3 variant, same tolerance
+        y3 = torch.full((N, Fo, Ho, Ho), float("nan"), device="cuda")
+        hp.stem_fwd(x.cuda(), w.cuda(), b.cuda(), y3, ws, k, s, p, x3=True)
+        close(y3, F.conv2d(x, w, b, stride=s, padding=p))
     dy = torch.randn(N, Fo, Ho, Ho, generator=g)
     wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     F.conv2d(x, wr, br, stride=s, padding=p).backward(dy)
@@ -127,6 +131,11 @@ def test_stem(hp, cfg):
     hp.stem_wgrad(x.cuda(), dy.cuda(), dW, db, ws, k, s, p)
     close(dW, wr.grad)
     close(db, br.grad)
+    if hp.stem_x3_supported(3, size, k, s, p) and size % 16 == 0:
+        dW3 = torch.full((Fo, 3, k, k), float("nan"), device="cuda"); db3 = torch.full((Fo,), float("nan"), device="cuda")
+        hp.stem_wgrad(x.cuda(), dy.cuda(), dW3, db3, ws, k, s, p, x3=True)
+        close(dW3, wr.grad)
+        close(db3, br.grad)
 
 
 @pytest.mark.parametrize("cfg", [(3, 64, 15, 6, 0), (2, 8, 15, 6, 0), (2, 32, 15, 3, 1), (2, 64, 20, 3, 1), (1, 128, 15, 6, 0)])
