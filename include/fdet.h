@@ -177,6 +177,14 @@ size_t fdet_conv3x3_wgrad_bf16x3_ws_bytes(int N, int Cin, int Cout, int H, int W
 int fdet_conv3x3_wgrad_bf16x3(const float* x, const float* dz, float* dW, float* db, void* ws,
                               size_t ws_bytes, int N, int Cin, int Cout, int H, int W, void* stream);
 
+/* Batched form: L <= 16 same-shape layers in ONE launch (+ one reduce launch).  h_x / h_dz / h_dW /
+ * h_db are HOST arrays of L device pointers.  Small layers (15x15) are launch/reduction-overhead
+ * bound one at a time; batched, every workgroup owns bands of a single layer and writes one slab. */
+size_t fdet_conv3x3_wgrad_bf16x3_batched_ws_bytes(int L, int N, int Cin, int Cout, int H, int W);
+int fdet_conv3x3_wgrad_bf16x3_batched(const float* const* h_x, const float* const* h_dz, float* const* h_dW,
+                                      float* const* h_db, int L, void* ws, size_t ws_bytes,
+                                      int N, int Cin, int Cout, int H, int W, void* stream);
+
 /* Residual-block tail for pooled blocks: out = maxpool_pool(c*drop_scale[n,f] + x)
  * (Dropout2d + skip add + MaxPool2d(2), models/PoolResnet.py:39-42).  pool in {1,2}.
  *   c,x [N,F,H,W]; drop_scale [N,F] or NULL; out [N,F,H/pool,W/pool]. */

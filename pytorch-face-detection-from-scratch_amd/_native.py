@@ -61,6 +61,8 @@ SIGNATURES = {
     "fdet_conv3x3_wgrad": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P]),
     "fdet_conv3x3_wgrad_bf16x3_ws_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "fdet_conv3x3_wgrad_bf16x3": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P]),
+    "fdet_conv3x3_wgrad_bf16x3_batched_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
+    "fdet_conv3x3_wgrad_bf16x3_batched": (_I, [_P, _P, _P, _P, _I, _P, _SZ, _I, _I, _I, _I, _I, _P]),
     "fdet_block_tail_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fdet_block_tail_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_stem_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I, _I, _I]),

@@ -240,6 +240,20 @@ class ConvStack:
         with self._t("head_bwd", N, hl):
             hp.head_bwd(h_last, masks["head"] if masks is not None else None, P["out.weight"], y, dy, dout,
                         G["out.weight"], G["out.bias"], ws, g.head_k, g.head_p)
+        pending = []          # (x, dz, weight name) of same-resolution convs awaiting one batched wgrad launch
+
+        def flush(hk_):
+            if not pending:
+                return
+            fl_ = self._conv_flops(N, hk_)
+            for i0 in range(0, len(pending), 16):
+                grp = pending[i0:i0 + 16]
+                wsb_ = self._workspace("wgrad_batched", hp.conv3x3_wgrad_batched_ws_bytes(len(grp), N, F_, F_, hk_, hk_), dev)
+                with self._t("conv3x3_wgrad", N, hk_, fl_ * len(grp), self._act_bytes(N, hk_, 2) * len(grp)):
+                    hp.conv3x3_wgrad_batched([p_[0] for p_ in grp], [p_[1] for p_ in grp],
+                                             [G[p_[2] + ".weight"] for p_ in grp], [G[p_[2] + ".bias"] for p_ in grp], wsb_)
+            pending.clear()
+
         for k in reversed(range(g.num_blocks)):
             hk, pool = self.lv[k]
             name = f"residual_blocks.{k}"
@@ -252,20 +266,32 @@ class ConvStack:
             if pool == 1:
                 de = dout
             fl = self._conv_flops(N, hk)
-            wws = self._workspace("wgrad", hp.conv3x3_wgrad_ws_bytes(N, F_, F_, hk, hk), dev)
-            wx3 = self.x3 and hp.wgrad_x3_supported(N, F_, F_, hk, hk)
-            with self._t("conv3x3_wgrad", N, hk, fl, self._act_bytes(N, hk, 2)):
-                hp.conv3x3_wgrad(a, dz2, G[name + ".conv2.weight"], G[name + ".conv2.bias"], wws, x3=wx3)
+            batched = self.x3 and hp.wgrad_x3_supported(N, F_, F_, hk, hk)
+            if not batched:
+                wws = self._workspace("wgrad", hp.conv3x3_wgrad_ws_bytes(N, F_, F_, hk, hk), dev)
+                with self._t("conv3x3_wgrad", N, hk, fl, self._act_bytes(N, hk, 2)):
+                    hp.conv3x3_wgrad(a, dz2, G[name + ".conv2.weight"], G[name + ".conv2.bias"], wws)
             dz1 = torch.empty_like(a)
             with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
                 hp.conv3x3_dgrad(dz2, self._wpk[name + ".conv2.b"], F_, dz1, act=a, slope=self.slope, x3=self.x3)
-            with self._t("conv3x3_wgrad", N, hk, fl, self._act_bytes(N, hk, 2)):
-                hp.conv3x3_wgrad(xin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], wws, x3=wx3)
-            dx = dz2                                   # reuse: dz2 is dead after its wgrad/dgrad
+            if not batched:
+                with self._t("conv3x3_wgrad", N, hk, fl, self._act_bytes(N, hk, 2)):
+                    hp.conv3x3_wgrad(xin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], wws)
+            dx = torch.empty_like(a) if batched else dz2      # batched: dz2 stays alive until the flush
             with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
                 hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], F_, dx, add=de, slope=self.slope, x3=self.x3)
             dout = dx
-            if after_block is not None:
+            if batched:
+                pending.append((a, dz2, name + ".conv2"))
+                pending.append((xin, dz1, name + ".conv1"))
+                # weight gradients of a run of same-resolution blocks go out in one launch
+                if k == 0 or self.lv[k - 1][0] != hk:
+                    flush(hk)
+                    if after_block is not None:
+                        for kk in range(k, g.num_blocks):
+                            if self.lv[kk][0] == hk:
+                                after_block(kk)
+            elif after_block is not None:
                 after_block(k)
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0

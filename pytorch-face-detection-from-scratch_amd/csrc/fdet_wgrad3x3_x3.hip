@@ -34,12 +34,13 @@ constexpr int XP = 8;         // front pad of the x rows
 __host__ __device__ constexpr int zreg(int vw) { return vw == 1 ? 32 : 64; }
 __host__ __device__ constexpr int xreg(int vw) { return vw == 1 ? 40 : 64; }
 
+constexpr int MAXL = 16;      // layers per batched launch
 struct WgX3Args {
-  const float* x;    // [N,Cin,H,W]
-  const float* dz;   // [N,Cout,H,W]
-  float* ws;         // [nslab][9][CoP][CiP]
-  float* wsb;        // [nslab][CoP]
-  int N, Cin, Cout, CoP, CiP, H, W, P, R, VR, QZ, PX, Kext, nbands;
+  const float* x[MAXL];    // per layer [N,Cin,H,W]
+  const float* dz[MAXL];   // per layer [N,Cout,H,W]
+  float* ws;               // [L][nslab][9][CoP][CiP]
+  float* wsb;              // [L][nslab][CoP]
+  int N, Cin, Cout, CoP, CiP, H, W, P, R, VR, QZ, PX, Kext, nbands, L, ncob;
   unsigned magic_h1;
 };
 
@@ -116,7 +117,9 @@ k_wgrad3x3_x3(const WgX3Args a) {
   __bf16* Xl = Xh + 32 * a.PX;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int cib = blockIdx.y, cob = blockIdx.z;
+  const int cib = blockIdx.y, cob = blockIdx.z % a.ncob, layer = blockIdx.z / a.ncob;
+  const float* __restrict__ gx = a.x[layer];
+  const float* __restrict__ gdz = a.dz[layer];
   const int m = wid % MTC, kh = wid / MTC;
   const int H1 = a.H + 1, P = a.P, W = a.W, R = a.R;
   const int nks = a.Kext / 16;
@@ -158,7 +161,7 @@ k_wgrad3x3_x3(const WgX3Args a) {
       const int v = (V0) + r_;                                                                    \
       const int n = fdiv(v, a.magic_h1), yy = v - n * H1 - 1;                                     \
       const bool rok = r_ < R && v < a.VR && yy >= 0;                                             \
-      const float* rowp = a.dz + ((size_t)n * a.Cout * a.H + yy) * W;                             \
+      const float* rowp = gdz + ((size_t)n * a.Cout * a.H + yy) * W;                             \
       _Pragma("unroll") for (int c_ = 0; c_ < ZCH; ++c_) {                                        \
         const int ch = co0 + c_ * 16 + chl;                                                       \
         pz[c_][r_] = (rok && lane_ok && ch < a.Cout)                                              \
@@ -169,7 +172,7 @@ k_wgrad3x3_x3(const WgX3Args a) {
       const int v = (V0) - 1 + r_;                                                                \
       const int n = fdiv(max(v, 0), a.magic_h1), yy = v - n * H1 - 1;                             \
       const bool rok = r_ < R + 2 && v >= 0 && v < a.VR && yy >= 0;                               \
-      const float* rowp = a.x + ((size_t)n * a.Cin * a.H + yy) * W;                               \
+      const float* rowp = gx + ((size_t)n * a.Cin * a.H + yy) * W;                               \
       _Pragma("unroll") for (int c_ = 0; c_ < XCH; ++c_) {                                        \
         const int ch = ci0 + c_ * 16 + chl;                                                       \
         px[c_][r_] = (rok && lane_ok && ch < a.Cin)                                               \
@@ -254,7 +257,7 @@ k_wgrad3x3_x3(const WgX3Args a) {
       __syncthreads();
     }
   }
-  const int s = blockIdx.x;
+  const int s = layer * gridDim.x + blockIdx.x;
   if (kh == 0) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -277,10 +280,15 @@ k_wgrad3x3_x3(const WgX3Args a) {
 }
 
 // Fixed-order reduction of the slabs (same scheme as fdet_wgrad3x3.hip)
+struct WgX3Red { float* dW[MAXL]; float* db[MAXL]; };
 __global__ void __launch_bounds__(1024)
-k_wgx3_reduce(const float* __restrict__ ws, const float* __restrict__ wsb, int nslab, int Cout, int Cin,
-              int CoP, int CiP, float* __restrict__ dW, float* __restrict__ db) {
+k_wgx3_reduce(const float* __restrict__ ws_all, const float* __restrict__ wsb_all, int nslab, int Cout, int Cin,
+              int CoP, int CiP, const WgX3Red out) {
   __shared__ float part[1024];
+  const float* __restrict__ ws = ws_all + (size_t)blockIdx.z * nslab * 9 * CoP * CiP;
+  const float* __restrict__ wsb = wsb_all + (size_t)blockIdx.z * nslab * CoP;
+  float* __restrict__ dW = out.dW[blockIdx.z];
+  float* __restrict__ db = out.db[blockIdx.z];
   const int tap = blockIdx.x;
   const int e = threadIdx.x & 255, ph = threadIdx.x >> 8;
   const int span = 4 * CiP;
@@ -316,7 +324,7 @@ unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) 
 
 struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw; size_t lds, ws_floats; bool ok; };
 
-WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W) {
+WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   WgX3Plan p{};
   p.P = (W + 1 + 7) / 8 * 8;
   p.VR = N * (H + 1) + 1;
@@ -338,7 +346,7 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W) {
     const size_t bytes = ((size_t)p.MTC * 32 * QZ + 32 * (size_t)PX) * 4;
     if (bytes > 150 * 1024) break;
     const long nb = (rows_total + r - 1) / r;
-    const long slots = 256 / ((p.CiP / 32) * (p.CoP / (p.MTC * 32)));   // workgroups along x so that the grid ~ 256
+    const long slots = std::max(1, 256 / ((p.CiP / 32) * (p.CoP / (p.MTC * 32)) * L));   // workgroups along x so that the grid ~ 256
     const long blk = std::max(1L, std::min(nb, slots));
     const double mfma = (double)(((nb + blk - 1) / blk) * blk * Kext) / ((double)rows_total * p.P);
     const double cost = mfma * (0.7 + 0.3 * (double)(r + 2) / r);
@@ -351,11 +359,11 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W) {
   p.QZ = p.Kext + 24; if (((p.QZ / 8) & 1) == 0) p.QZ += 8;
   p.PX = p.Kext + 2 * p.P + 8; if (((p.PX / 8) & 1) == 0) p.PX += 8;
   p.nbands = (rows_total + p.R - 1) / p.R;
-  const long slots = 256 / ((p.CiP / 32) * (p.CoP / (p.MTC * 32)));
+  const long slots = std::max(1, 256 / ((p.CiP / 32) * (p.CoP / (p.MTC * 32)) * L));
   p.nblk = (int)std::max(1L, std::min((long)p.nbands, slots));
   p.lds = ((size_t)p.MTC * 32 * p.QZ + 32 * (size_t)p.PX) * 4;
   p.lds = std::max(p.lds, (size_t)p.MTC * 144 * 64 * 4);
-  p.ws_floats = (size_t)p.nblk * 9 * p.CoP * p.CiP + (size_t)p.nblk * p.CoP;
+  p.ws_floats = (size_t)L * ((size_t)p.nblk * 9 * p.CoP * p.CiP + (size_t)p.nblk * p.CoP);
   return p;
 }
 
@@ -372,29 +380,51 @@ void launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) 
 
 }  // namespace
 
+static int run_wg_x3(const float* const* xs, const float* const* dzs, float* const* dWs, float* const* dbs, int L,
+                     void* ws, size_t ws_bytes, int N, int Cin, int Cout, int H, int W, hipStream_t st) {
+  const WgX3Plan p = plan_x3(N, Cin, Cout, H, W, L);
+  FDET_REQUIRE(p.ok, "conv3x3_wgrad_bf16x3: no tiling for N=%d H=%d W=%d (row must fit 16 vector lanes)", N, H, W);
+  if (ws_bytes < p.ws_floats * 4)
+    return fail(FDET_EWORKSPACE, "conv3x3_wgrad_bf16x3: workspace %zu < %zu bytes", ws_bytes, p.ws_floats * 4);
+  WgX3Args a{};
+  WgX3Red r{};
+  for (int l = 0; l < L; ++l) { a.x[l] = xs[l]; a.dz[l] = dzs[l]; r.dW[l] = dWs[l]; r.db[l] = dbs[l]; }
+  a.ws = (float*)ws; a.wsb = (float*)ws + (size_t)L * p.nblk * 9 * p.CoP * p.CiP;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.CoP = p.CoP; a.CiP = p.CiP; a.H = H; a.W = W; a.P = p.P; a.R = p.R;
+  a.VR = p.VR; a.QZ = p.QZ; a.PX = p.PX; a.Kext = p.Kext; a.nbands = p.nbands; a.magic_h1 = magic_of(H + 1);
+  a.L = L; a.ncob = p.CoP / (p.MTC * 32);
+  dim3 grid(p.nblk, p.CiP / 32, a.ncob * L);
+  if (p.MTC == 2) launch_x3<2>(a, p, grid, st); else launch_x3<1>(a, p, grid, st);
+  if (int rc = check_launch("fdet_conv3x3_wgrad_bf16x3")) return rc;
+  hipLaunchKernelGGL(k_wgx3_reduce, dim3(9, (Cout + 3) / 4, L), dim3(1024), 0, st, a.ws, a.wsb, p.nblk, Cout, Cin, p.CoP,
+                     p.CiP, r);
+  return check_launch("fdet_conv3x3_wgrad_bf16x3(reduce)");
+}
+
 extern "C" size_t fdet_conv3x3_wgrad_bf16x3_ws_bytes(int N, int Cin, int Cout, int H, int W) {
   if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
   const WgX3Plan p = plan_x3(N, Cin, Cout, H, W);
   return p.ok ? p.ws_floats * 4 : 0;
 }
 
+extern "C" size_t fdet_conv3x3_wgrad_bf16x3_batched_ws_bytes(int L, int N, int Cin, int Cout, int H, int W) {
+  if (L <= 0 || L > MAXL || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  const WgX3Plan p = plan_x3(N, Cin, Cout, H, W, L);
+  return p.ok ? p.ws_floats * 4 : 0;
+}
+
 extern "C" int fdet_conv3x3_wgrad_bf16x3(const float* x, const float* dz, float* dW, float* db, void* ws,
                                          size_t ws_bytes, int N, int Cin, int Cout, int H, int W, void* stream) {
-  FDET_REQUIRE(x && dz && dW && ws, "conv3x3_wgrad_bf16x3: null pointer");
+  FDET_REQUIRE(x && dz && dW && db && ws, "conv3x3_wgrad_bf16x3: null pointer");
   FDET_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_wgrad_bf16x3: bad shape");
-  const WgX3Plan p = plan_x3(N, Cin, Cout, H, W);
-  FDET_REQUIRE(p.ok, "conv3x3_wgrad_bf16x3: no tiling for N=%d H=%d W=%d (row must fit 16 vector lanes)", N, H, W);
-  if (ws_bytes < p.ws_floats * 4)
-    return fail(FDET_EWORKSPACE, "conv3x3_wgrad_bf16x3: workspace %zu < %zu bytes", ws_bytes, p.ws_floats * 4);
-  WgX3Args a;
-  a.x = x; a.dz = dz; a.ws = (float*)ws; a.wsb = (float*)ws + (size_t)p.nblk * 9 * p.CoP * p.CiP;
-  a.N = N; a.Cin = Cin; a.Cout = Cout; a.CoP = p.CoP; a.CiP = p.CiP; a.H = H; a.W = W; a.P = p.P; a.R = p.R;
-  a.VR = p.VR; a.QZ = p.QZ; a.PX = p.PX; a.Kext = p.Kext; a.nbands = p.nbands; a.magic_h1 = magic_of(H + 1);
-  dim3 grid(p.nblk, p.CiP / 32, p.CoP / (p.MTC * 32));
-  hipStream_t st = (hipStream_t)stream;
-  if (p.MTC == 2) launch_x3<2>(a, p, grid, st); else launch_x3<1>(a, p, grid, st);
-  if (int rc = check_launch("fdet_conv3x3_wgrad_bf16x3")) return rc;
-  hipLaunchKernelGGL(k_wgx3_reduce, dim3(9, (Cout + 3) / 4), dim3(1024), 0, st, a.ws, a.wsb, p.nblk, Cout, Cin, p.CoP,
-                     p.CiP, dW, db);
-  return check_launch("fdet_conv3x3_wgrad_bf16x3(reduce)");
+  return run_wg_x3(&x, &dz, &dW, &db, 1, ws, ws_bytes, N, Cin, Cout, H, W, (hipStream_t)stream);
+}
+
+extern "C" int fdet_conv3x3_wgrad_bf16x3_batched(const float* const* h_x, const float* const* h_dz, float* const* h_dW,
+                                                 float* const* h_db, int L, void* ws, size_t ws_bytes, int N, int Cin,
+                                                 int Cout, int H, int W, void* stream) {
+  FDET_REQUIRE(h_x && h_dz && h_dW && h_db && ws && L >= 1 && L <= MAXL, "conv3x3_wgrad_bf16x3_batched: bad arguments (L=%d, max %d)", L, MAXL);
+  for (int l = 0; l < L; ++l) FDET_REQUIRE(h_x[l] && h_dz[l] && h_dW[l] && h_db[l], "conv3x3_wgrad_bf16x3_batched: null pointer in layer %d", l);
+  FDET_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_wgrad_bf16x3_batched: bad shape");
+  return run_wg_x3(h_x, h_dz, h_dW, h_db, L, ws, ws_bytes, N, Cin, Cout, H, W, (hipStream_t)stream);
 }

@@ -237,6 +237,30 @@ def conv3x3_wgrad(x, dz, dW, db, ws, x3: bool = False):
              Nn, cin, cout, H, W, stream()), "fdet_conv3x3_wgrad")
 
 
+def conv3x3_wgrad_batched_ws_bytes(L, Nn, cin, cout, H, W) -> int:
+    return int(lib().fdet_conv3x3_wgrad_bf16x3_batched_ws_bytes(L, Nn, cin, cout, H, W))
+
+
+def conv3x3_wgrad_batched(xs, dzs, dWs, dbs, ws):
+    """bf16x3 weight gradients of L <= 16 same-shape layers in one launch (+ one reduce)."""
+    L = len(xs)
+    if not (1 <= L <= 16 and len(dzs) == len(dWs) == len(dbs) == L):
+        raise ValueError("conv3x3_wgrad_batched: 1..16 layers, equal list lengths")
+    Nn, cin, H, W = xs[0].shape
+    cout = dzs[0].shape[1]
+    for x, dz, dW, db in zip(xs, dzs, dWs, dbs):
+        _chk4(x, (Nn, cin, H, W), "x")
+        _chk4(dz, (Nn, cout, H, W), "dz")
+        _chk4(dW, (cout, cin, 3, 3), "dW")
+        _chk4(db, (cout,), "db")
+    import ctypes
+    arr = ctypes.c_void_p * L
+    hx, hdz = arr(*[ptr(t) for t in xs]), arr(*[ptr(t) for t in dzs])
+    hdW, hdb = arr(*[ptr(t) for t in dWs]), arr(*[ptr(t) for t in dbs])
+    check(lib().fdet_conv3x3_wgrad_bf16x3_batched(hx, hdz, hdW, hdb, L, ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
+                                                  Nn, cin, cout, H, W, stream()), "fdet_conv3x3_wgrad_bf16x3_batched")
+
+
 def block_tail_fwd(c, x, drop_scale, out, pool: int):
     Nn, F_, H, W = c.shape
     _chk4(x, c.shape, "x")

@@ -116,7 +116,8 @@ def test_fused_train_steps_vs_oracle(fd, kind, F, size, S, nb, B):
     for n, p in model.named_parameters():
         d = (p.detach().cpu() - P[n]).abs()
         assert float(d.max()) <= 4.1e-4, n
-        assert float((d > 2e-6).float().mean()) < 0.03, n
+        # sign flips of noise-level gradient entries under Adam (see above): a few per tensor at most
+        assert int((d > 2e-6).sum()) <= max(3, int(0.03 * d.numel())), n
 
 
 def test_trained_small_archive_demo_path(fd, golden):
