@@ -64,6 +64,41 @@ def cpu_baseline(filters, size, S, sample_bs, steps):
                       f"torch CPU fp32, {threads} threads, {dt:.1f} s"}
 
 
+def infer_bench(model, size, device, frames=100, warm=20):
+    """BASELINE.json: "infer FPS incl. NMS".  (1) the reference's demo path (demo_model.py:17-21): one
+    uint8 frame stacked twice, forward(predict=1) = /255 -> conv stack -> sigmoid -> decode -> NMS of
+    image 0, result read back by the host every frame; (2) batched serving: 256 uint8 frames per
+    call, decode + NMS of every image on the device, counts read back once per batch."""
+    model.eval()
+    g = torch.Generator().manual_seed(0)
+    u8 = torch.randint(0, 256, (3, size, size), dtype=torch.uint8, generator=g)
+    pair = torch.stack([u8, u8]).to(device)
+    with torch.no_grad():
+        for _ in range(warm):
+            model(pair, predict=torch.tensor(1))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            det = model(pair, predict=torch.tensor(1))
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t0) / frames
+        big = torch.randint(0, 256, (256, 3, size, size), dtype=torch.uint8, generator=g).to(device)
+        for _ in range(2):
+            model.non_max_suppression(model(model._preprocess(big)))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            outs = model.non_max_suppression(model(model._preprocess(big)))
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t0) / reps
+    model.train()
+    return {"demo_path_ms_per_frame": round(dt1 * 1e3, 3), "demo_path_fps": round(1.0 / dt1, 1),
+            "batched_fps": round(256 / dtb, 1), "batched_ms_per_256": round(dtb * 1e3, 3),
+            "what": "uint8 3x480x480 frames -> /255 -> PoolResnet-medium -> decode -> greedy NMS (thresholds 0.5/0.5, "
+                    "random-init weights); demo path = 2 stacked frames per call, boxes of image 0 read by the host"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,8 +214,10 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": roof, "kernel_ms_per_step": breakdown, "final_loss": round(loss_val, 4),
         }
+        if world == 1:
+            out["inference"] = infer_bench(model, size, device)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(F_, size, S, sample_bs=64, steps=3)
+            out["cpu_baseline"] = cpu_baseline(F_, size, S, sample_bs=64, steps=24)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -118,6 +118,18 @@ int fdet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    int step, double lr, double beta1, double beta2, double eps, float grad_scale,
                    void* stream);
 
+/* Bilinear Resize fused with the /255 normalisation: replaces `self.resize(x) / 255.0`
+ * (models/PoolResnet.py:91,95; models/Resnet.py likewise) and `Resize(...)(x); x / 255.0`
+ * (models/BaseModel.py:64-65), i.e. torchvision 0.11.2 transforms.Resize on tensors =
+ * F.interpolate(mode="bilinear", align_corners=False), no antialias.
+ *   u8 : src [N,C,Hs,Ws] uint8 -> dst [N,C,Hd,Wd] f32 = round_half_even(interp) / 255   (the uint8 round trip)
+ *   f32: src [N,C,Hs,Ws] f32   -> dst = interp / divisor                                 (no rounding)
+ * Same-size dimensions are the identity. */
+int fdet_resize_bilinear_u8_norm(const uint8_t* src, float* dst, int N, int C, int Hs, int Ws,
+                                 int Hd, int Wd, void* stream);
+int fdet_resize_bilinear_f32_norm(const float* src, float* dst, int N, int C, int Hs, int Ws,
+                                  int Hd, int Wd, float divisor, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Conv stack (PoolResnet / Resnet): fp32 implicit GEMM on v_mfma_f32_32x32x2_f32
  * ------------------------------------------------------------------------------------- */
@@ -171,8 +183,9 @@ int fdet_conv3x3_wgrad(const float* x, const float* dz, float* dW, float* db, vo
                        size_t ws_bytes, int N, int Cin, int Cout, int H, int W, void* stream);
 
 /* bf16x3 variant of the weight gradient (same arguments/results within ~1e-5 of the tensor's scale;
- * see the bf16x3 note above).  Needs W/VW <= 16 lanes per row (VW = 4, 2, 1 for W%4==0, W%2==0, else):
- * W <= 64; fdet_conv3x3_wgrad_bf16x3_ws_bytes returns 0 when the shape is not supported. */
+ * see the bf16x3 note above).  Rows of up to 16 vector lanes (VW = 4, 2, 1 floats for W%4==0, W%2==0,
+ * else) are staged whole; wider rows need W % 4 == 0 and are cut into 56-column segments.
+ * fdet_conv3x3_wgrad_bf16x3_ws_bytes returns 0 when the shape is not supported. */
 size_t fdet_conv3x3_wgrad_bf16x3_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int fdet_conv3x3_wgrad_bf16x3(const float* x, const float* dz, float* dW, float* db, void* ws,
                               size_t ws_bytes, int N, int Cin, int Cout, int H, int W, void* stream);
@@ -184,6 +197,29 @@ size_t fdet_conv3x3_wgrad_bf16x3_batched_ws_bytes(int L, int N, int Cin, int Cou
 int fdet_conv3x3_wgrad_bf16x3_batched(const float* const* h_x, const float* const* h_dz, float* const* h_dW,
                                       float* const* h_db, int L, void* ws, size_t ws_bytes,
                                       int N, int Cin, int Cout, int H, int W, void* stream);
+
+/* Residual-block CHAIN at one resolution, running activation resident in LDS (bf16x3 arithmetic).
+ * `nblocks` consecutive un-pooled ResidualBlocks (models/PoolResnet.py:33-43 / models/Resnet.py:30-40 with
+ * pool == 1) in ONE launch, one workgroup per image; HBM only sees the tensors kept for backward.
+ * Needs 64 channels and H*roundup4(W+1) <= 256 (15x15, 10x10 ...): fdet_block_chain_supported.
+ * All h_* arguments are HOST arrays of `nblocks` DEVICE pointers.
+ *   forward : a_k = lrelu(conv1_k(h)); c_k = lrelu(conv2_k(a_k)); h <- c_k*scale_k[n,f] + h
+ *     x [N,64,H,W]; h_wpk1/h_wpk2: forward panels of fdet_pack_conv3x3_weights_bf16x3; h_b1/h_b2 biases;
+ *     h_scale: [N,64] dropout scales (array or entries NULL = eval); h_a/h_c: where to keep a_k / c_k
+ *     (array or entries NULL: not kept); h_out: block outputs (entries may be NULL except the last).
+ *   backward: dz2_k = dout*scale_k*lrelu'(c_k); dz1_k = conv2_k^T(dz2_k)*lrelu'(a_k);
+ *             dout <- conv1_k^T(dz1_k) + dout, for k = nblocks-1 .. 0; dx = final dout.
+ *     h_wpk1b/h_wpk2b: backward panels; h_dz1/h_dz2 [N,64,H,W] are written (operands of the weight gradients). */
+int fdet_block_chain_supported(int F, int H, int W);
+int fdet_block_chain_fwd_bf16x3(const float* x, const void* const* h_wpk1, const float* const* h_b1,
+                                const void* const* h_wpk2, const float* const* h_b2,
+                                const float* const* h_scale, float* const* h_a, float* const* h_c,
+                                float* const* h_out, int nblocks, int N, int F, int H, int W, float slope,
+                                void* stream);
+int fdet_block_chain_bwd_bf16x3(const float* dout, const void* const* h_wpk1b, const void* const* h_wpk2b,
+                                const float* const* h_scale, const float* const* h_a, const float* const* h_c,
+                                float* const* h_dz1, float* const* h_dz2, float* dx, int nblocks, int N, int F,
+                                int H, int W, float slope, void* stream);
 
 /* Residual-block tail for pooled blocks: out = maxpool_pool(c*drop_scale[n,f] + x)
  * (Dropout2d + skip add + MaxPool2d(2), models/PoolResnet.py:39-42).  pool in {1,2}.

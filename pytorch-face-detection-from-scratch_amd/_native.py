@@ -50,6 +50,8 @@ SIGNATURES = {
     "fdet_reduce_bounding_boxes": (_I, [_P, _I, _I, _F, _D, _F, _F, _P, _P, _P]),
     "fdet_step_metrics": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "fdet_u8_to_f32_norm": (_I, [_P, _P, _SZ, _P]),
+    "fdet_resize_bilinear_u8_norm": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fdet_resize_bilinear_f32_norm": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_adam_step": (_I, [_P, _P, _P, _P, _SZ, _I, _D, _D, _D, _D, _F, _P]),
     "fdet_pack_conv3x3_weights": (_I, [_P, _I, _I, _P, _P, _P]),
     "fdet_conv3x3_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
@@ -63,6 +65,9 @@ SIGNATURES = {
     "fdet_conv3x3_wgrad_bf16x3": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P]),
     "fdet_conv3x3_wgrad_bf16x3_batched_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "fdet_conv3x3_wgrad_bf16x3_batched": (_I, [_P, _P, _P, _P, _I, _P, _SZ, _I, _I, _I, _I, _I, _P]),
+    "fdet_block_chain_supported": (_I, [_I, _I, _I]),
+    "fdet_block_chain_fwd_bf16x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_block_chain_bwd_bf16x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_block_tail_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fdet_block_tail_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_stem_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I, _I, _I]),

@@ -171,6 +171,20 @@ class ConvStack:
             self._ws[name] = t
         return t
 
+    def _chain_run(self, k: int) -> int:
+        """Number of consecutive un-pooled blocks starting at block k that can run as one
+        LDS-resident chain (bf16x3, 64 channels, small maps); 0/1 = use the per-layer kernels."""
+        import os
+        if not self.x3 or os.environ.get("FDET_CHAIN", "1") == "0":
+            return 0
+        hk, pool = self.lv[k]
+        if pool != 1 or not hp.block_chain_supported(self.geo.filters, hk, hk):
+            return 0
+        run = 1
+        while k + run < len(self.lv) and self.lv[k + run] == (hk, 1) and run < 16:
+            run += 1
+        return run
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], masks: Optional[Dict[str, torch.Tensor]] = None,
                 save: bool = False):
@@ -191,7 +205,28 @@ class ConvStack:
             hp.stem_fwd(x, P["conv1.weight"], P["conv1.bias"], h, ws, g.stem_k, g.stem_s, g.stem_p,
                         x3=self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p))
         saved = {"x": x, "blocks": [], "masks": masks} if save else None
-        for k, (hk, pool) in enumerate(self.lv):
+        k = -1
+        while k + 1 < len(self.lv):
+            k += 1
+            hk, pool = self.lv[k]
+            run = self._chain_run(k)
+            if run > 1:
+                # blocks k .. k+run-1 keep their activation on the CU: one launch (fdet_block_chain_fwd_bf16x3)
+                names = [f"residual_blocks.{kk}" for kk in range(k, k + run)]
+                a_l = [torch.empty(N, F_, hk, hk, dtype=F32, device=dev) for _ in names] if save else None
+                c_l = [torch.empty(N, F_, hk, hk, dtype=F32, device=dev) for _ in names] if save else None
+                o_l = [torch.empty(N, F_, hk, hk, dtype=F32, device=dev) if (save or i == run - 1) else None
+                       for i in range(run)]
+                with self._t("chain_fwd", N, hk, 2 * run * self._conv_flops(N, hk), self._act_bytes(N, hk, 1 + (3 * run if save else 1))):
+                    hp.block_chain_fwd(h, [self._wpk[nm + ".conv1.f"] for nm in names], [P[nm + ".conv1.bias"] for nm in names],
+                                       [self._wpk[nm + ".conv2.f"] for nm in names], [P[nm + ".conv2.bias"] for nm in names],
+                                       [masks[nm] for nm in names] if masks is not None else None, a_l, c_l, o_l, self.slope)
+                if save:
+                    for i in range(run):
+                        saved["blocks"].append((h if i == 0 else o_l[i - 1], a_l[i], c_l[i]))
+                h = o_l[-1]
+                k += run - 1
+                continue
             name = f"residual_blocks.{k}"
             sc = masks[name] if masks is not None else None
             a = torch.empty(N, F_, hk, hk, dtype=F32, device=dev)
@@ -254,8 +289,45 @@ class ConvStack:
                                              [G[p_[2] + ".weight"] for p_ in grp], [G[p_[2] + ".bias"] for p_ in grp], wsb_)
             pending.clear()
 
-        for k in reversed(range(g.num_blocks)):
+        # runs of blocks that went through the forward chain come back through the backward chain
+        chain_start = {}
+        kk = 0
+        while kk < g.num_blocks:
+            run = self._chain_run(kk)
+            if run > 1:
+                chain_start[kk + run - 1] = kk
+                kk += run
+            else:
+                kk += 1
+        k = g.num_blocks
+        while k > 0:
+            k -= 1
             hk, pool = self.lv[k]
+            if k in chain_start:
+                k0 = chain_start[k]
+                ks = list(range(k0, k + 1))
+                names = [f"residual_blocks.{q}" for q in ks]
+                dz1_l = [torch.empty_like(saved["blocks"][q][1]) for q in ks]
+                dz2_l = [torch.empty_like(saved["blocks"][q][1]) for q in ks]
+                dx = torch.empty_like(dout)
+                with self._t("chain_bwd", N, hk, 2 * len(ks) * self._conv_flops(N, hk), self._act_bytes(N, hk, 2 + 4 * len(ks))):
+                    hp.block_chain_bwd(dout, [self._wpk[nm + ".conv1.b"] for nm in names], [self._wpk[nm + ".conv2.b"] for nm in names],
+                                       [masks[nm] for nm in names] if masks is not None else None,
+                                       [saved["blocks"][q][1] for q in ks], [saved["blocks"][q][2] for q in ks],
+                                       dz1_l, dz2_l, dx, self.slope)
+                for i in reversed(range(len(ks))):
+                    q = ks[i]
+                    pending.append((saved["blocks"][q][1], dz2_l[i], names[i] + ".conv2"))
+                    pending.append((saved["blocks"][q][0], dz1_l[i], names[i] + ".conv1"))
+                dout = dx
+                k = k0
+                if k == 0 or self.lv[k - 1][0] != hk:
+                    flush(hk)
+                    if after_block is not None:
+                        for q in range(k, g.num_blocks):
+                            if self.lv[q][0] == hk:
+                                after_block(q)
+                continue
             name = f"residual_blocks.{k}"
             xin, a, c = saved["blocks"][k]
             sc = masks[name] if masks is not None else None

@@ -5,210 +5,13 @@
 // fp32 FMA chain (tests: 1e-4) while v_mfma_f32_32x32x16_bf16 delivers 16x the K per clock of the
 // f32 MFMA: three passes are ~5x faster, which moves the 3x3 convs from MFMA-bound to HBM-bound.
 //
-// Same "flattened padded rows" implicit GEMM as fdet_conv3x3.hip, but the MFMA K index is 16
-// input channels at ONE tap, so LDS tiles are channel-innermost:
-//   B: four arrays  {hi,lo} x {k-half h}  of  [position][8 x bf16]   (16 B per position)
-//   A: {hi,lo} x [tap][h][co][8 x bf16]                              (pre-split panels in HBM)
-// A lane's fragment is one aligned 16-byte ds_read_b128; consecutive lanes read consecutive
-// 16-byte slots (conflict-free); a tap is still a constant position offset.
-// The fp32 -> (hi,lo) split of activations happens while staging global -> registers -> LDS.
-// One workgroup (4 waves, one per SIMD, 512-register budget) per CU; double-buffered LDS.
-#include "fdet_conv_common.h"
-
-using namespace fdet;
+// This file: weight-panel packing, tile selection and the C-ABI entry points.  The kernels live in
+// fdet_conv3x3_x3_kernel.inc, compiled once per epilogue mode (fdet_conv3x3_x3_m*.hip).
+#include "fdet_conv3x3_x3.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int CK16 = 16;     // input channels per chunk (= MFMA K)
-constexpr int NBS = 5;       // B staging slots per thread (8 fp32 loads each)
-
-struct X3Args {
-  ConvArgs c;                // x, bias, epilogue pointers, geometry (WP, R, VR, nbands, mode ...)
-  const bf16x8* a_hi;        // [Cin/16][9][2][CoP] x 8 bf16
-  const bf16x8* a_lo;
-  int PT;                    // positions per B array (cap + 2*WP + 3)
-  int p_in;                  // (R+2)*W staged positions per k-half
-  unsigned magic_w;
-};
-
-__device__ __forceinline__ void split8(const float (&f)[8], bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)f[j];
-    hi[j] = h;
-    lo[j] = (__bf16)(f[j] - (float)h);
-  }
-}
-
-template <int MT, int NT>
-__global__ void __launch_bounds__(NTHR, 1)
-k_conv3x3_x3(const X3Args p) {
-  const ConvArgs& a = p.c;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int MB = MT * 32;
-  constexpr int A_UNITS = 9 * 2 * MB;                 // 16-byte units per A array per chunk
-  constexpr int NA = (2 * A_UNITS + NTHR - 1) / NTHR; // hi and lo
-  const int PT = p.PT, WP = a.WP;
-  const int buf_units = 2 * A_UNITS + 4 * PT;         // 16-byte units per buffer
-  bf16x8* lds = reinterpret_cast<bf16x8*>(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int band = blockIdx.x, mb = blockIdx.y;
-  const int v0 = band * a.R;
-  const int H1 = a.H + 1;
-  const size_t HW = (size_t)a.H * a.W;
-
-  {  // zero both buffers: halo positions of the B arrays are never written again
-    f32x4* z = reinterpret_cast<f32x4*>(smem);
-    for (int t = tid; t < 2 * buf_units; t += NTHR) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  // ---- B staging geometry (chunk invariant): slot -> (k-half, tile row, column)
-  int b_src[NBS], b_dst[NBS];                         // src: element offset for channel 8h of chunk 0 (-1: skip)
-#pragma unroll
-  for (int s = 0; s < NBS; ++s) {
-    const int it = s * NTHR + tid;
-    b_src[s] = -1; b_dst[s] = 0;
-    if (it < 2 * p.p_in) {
-      const int h = it >= p.p_in ? 1 : 0;
-      const int pp = it - h * p.p_in;
-      const int tr = fdiv(pp, p.magic_w), ix = pp - tr * a.W;
-      const int v = v0 - 1 + tr;
-      if (v >= 0 && v < a.VR) {
-        const int n = fdiv(v, a.magic_h1), yy = v - n * H1 - 1;
-        if (yy >= 0) {
-          b_src[s] = ((n * a.Cin + 8 * h) * a.H + yy) * a.W + ix;
-          b_dst[s] = h * PT + tr * WP + 1 + ix;       // unit index inside the hi array pair; lo = +2*PT
-        }
-      }
-    }
-  }
-  const int a_chunk_units = 9 * 2 * a.CoP;            // units per chunk per array in HBM
-  bf16x8 pa[NA];
-  float pb[NBS][8];
-#define X3_ISSUE_LOADS(C16)                                                                        \
-  {                                                                                                \
-    _Pragma("unroll") for (int s_ = 0; s_ < NA; ++s_) {                                            \
-      const int u_ = min(tid + s_ * NTHR, 2 * A_UNITS - 1);                                        \
-      const int lo_ = u_ >= A_UNITS ? 1 : 0;                                                       \
-      const int r_ = u_ - lo_ * A_UNITS;                                                           \
-      const int th_ = r_ / MB, co_ = r_ - th_ * MB;                                                \
-      const bf16x8* src_ = (lo_ ? p.a_lo : p.a_hi) + (size_t)(C16) * a_chunk_units + th_ * a.CoP + mb * MB + co_; \
-      pa[s_] = *src_;                                                                              \
-    }                                                                                              \
-    const float* xs_ = a.x + (size_t)(C16) * CK16 * HW;                                            \
-    _Pragma("unroll") for (int s_ = 0; s_ < NBS; ++s_) {                                           \
-      const float* q_ = xs_ + max(b_src[s_], 0);                                                   \
-      _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) pb[s_][j_] = q_[j_ * HW];                   \
-    }                                                                                              \
-  }
-#define X3_WRITE_LDS(BUF)                                                                          \
-  {                                                                                                \
-    bf16x8* buf_ = (BUF);                                                                          \
-    _Pragma("unroll") for (int s_ = 0; s_ < NA; ++s_) {                                            \
-      const int u_ = tid + s_ * NTHR;                                                              \
-      if (u_ < 2 * A_UNITS) buf_[u_] = pa[s_];                                                     \
-    }                                                                                              \
-    bf16x8* B_ = buf_ + 2 * A_UNITS;                                                               \
-    _Pragma("unroll") for (int s_ = 0; s_ < NBS; ++s_) {                                           \
-      if (b_src[s_] >= 0) {                                                                        \
-        bf16x8 hi_, lo_;                                                                           \
-        split8(pb[s_], hi_, lo_);                                                                  \
-        B_[b_dst[s_]] = hi_;                                                                       \
-        B_[b_dst[s_] + 2 * PT] = lo_;                                                              \
-      }                                                                                            \
-    }                                                                                              \
-  }
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-  int tapoff[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) tapoff[t] = (t / 3) * WP + (t % 3);
-
-  const int qwave = wid * NT * 32;
-  const int a_off = half * MB + l31;                           // + tap*2*MB + m*32 ; lo: + A_UNITS
-  const int b_off = 2 * A_UNITS + half * PT + qwave + l31;     // + tapoff + n*32   ; lo: + 2*PT
-
-  X3_ISSUE_LOADS(0)
-  __syncthreads();                       // zero fill complete
-  X3_WRITE_LDS(lds)
-  __syncthreads();
-
-  const int nch = a.Cin / CK16;
-  for (int c = 0; c < nch; ++c) {
-    const bf16x8* buf = lds + (c & 1) * buf_units;
-    if (c + 1 < nch) X3_ISSUE_LOADS(c + 1)
-    const bf16x8* Aw = buf + a_off;
-    const bf16x8* Bw = buf + b_off;
-    // fragments of tap t+1 are fetched before the MFMAs of tap t
-    bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) { ah[0][m] = Aw[m * 32]; al[0][m] = Aw[A_UNITS + m * 32]; }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) { bh[0][n] = Bw[tapoff[0] + n * 32]; bl[0][n] = Bw[2 * PT + tapoff[0] + n * 32]; }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int cur = t & 1, nxt = cur ^ 1;
-      if (t + 1 < 9) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          ah[nxt][m] = Aw[(t + 1) * 2 * MB + m * 32];
-          al[nxt][m] = Aw[A_UNITS + (t + 1) * 2 * MB + m * 32];
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          bh[nxt][n] = Bw[tapoff[t + 1] + n * 32];
-          bl[nxt][n] = Bw[2 * PT + tapoff[t + 1] + n * 32];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][m], bl[cur][n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][m], bh[cur][n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][m], bh[cur][n], acc[m][n], 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (c + 1 < nch) X3_WRITE_LDS(lds + ((c + 1) & 1) * buf_units)
-    __syncthreads();
-  }
-
-  // ---- epilogue (shared with the fp32 kernel: same accumulator layout)
-  const int qlimit = a.R * WP;
-  bool okn[NT];
-  size_t basen[NT];
-  int imgn[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int q = qwave + n * 32 + l31;
-    const int tr = q / WP, ox = q - tr * WP;
-    const int v = v0 + tr;
-    const int img = v / H1, oy = v - img * H1 - 1;
-    okn[n] = (q < qlimit) && (ox < a.W) && (v < a.VR) && (oy >= 0);
-    basen[n] = ((size_t)img * a.Cout * a.H + oy) * a.W + ox;
-    imgn[n] = img;
-  }
-  const int cob0 = mb * MB + 4 * half;
-  switch (a.mode) {
-    case EPI_FWD_FULL: epilogue<MT, NT, EPI_FWD_FULL>(a, acc, okn, basen, imgn, cob0, HW); break;
-    case EPI_FWD_BOTH: epilogue<MT, NT, EPI_FWD_BOTH>(a, acc, okn, basen, imgn, cob0, HW); break;
-    case EPI_FWD_OUT: epilogue<MT, NT, EPI_FWD_OUT>(a, acc, okn, basen, imgn, cob0, HW); break;
-    case EPI_DGRAD_ACT: epilogue<MT, NT, EPI_DGRAD_ACT>(a, acc, okn, basen, imgn, cob0, HW); break;
-    case EPI_DGRAD_ADD: epilogue<MT, NT, EPI_DGRAD_ADD>(a, acc, okn, basen, imgn, cob0, HW); break;
-    default: epilogue<MT, NT, EPI_GENERIC>(a, acc, okn, basen, imgn, cob0, HW); break;
-  }
-}
+long long* g_probe_stamps = nullptr;   // set only by the diagnostic build's fdet_x3_probe_set
 
 // ---------------------------------------------------------------------------------------
 // weight panels: split fp32 OIHW weights into bf16 hi/lo, K-major per 16-channel chunk
@@ -246,18 +49,31 @@ k_pack3x3_x3(const float* __restrict__ w, int Cout, int Cin, int CoP, int CiP, b
   }
 }
 
-template <int MT, int NT>
-int launch_x3(const X3Args& p, size_t lds, dim3 grid, hipStream_t st) {
-  (void)hipFuncSetAttribute((const void*)k_conv3x3_x3<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_conv3x3_x3<MT, NT>), grid, dim3(NTHR), lds, st, p);
-  return check_launch("fdet_conv3x3_bf16x3");
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
 }
 
 int run_x3(ConvArgs a, hipStream_t st) {
-  a.WP = a.W + 1;
+  // rows of up to 64 columns: the small-tile kernel (two workgroups per CU) is the faster one
+  // (FDET_CONV_KERNEL=general forces the persistent kernel)
+  {
+    const char* e = getenv("FDET_CONV_KERNEL");
+    if (a.W <= 64 && !(e && e[0] == 'g')) {
+      const int rc = fdet_x3_sb_run(a, st);
+      if (rc != 1) return rc;
+    }
+  }
   a.VR = a.N * (a.H + 1) + 1;
   if (a.VR >= (1 << 20)) return fail(FDET_EINVAL, "conv3x3_bf16x3: N*(H+1)=%d virtual rows exceed the index range", a.VR);
-  if ((size_t)a.N * a.Cin * a.H * a.W >= (size_t)1 << 31) return fail(FDET_EINVAL, "conv3x3_bf16x3: tensor too large for 32-bit offsets");
+  if ((size_t)a.N * (size_t)max(a.Cin, a.Cout) * a.H * a.W >= (size_t)1 << 31)
+    return fail(FDET_EINVAL, "conv3x3_bf16x3: tensor too large for 32-bit offsets");
   a.CoP = (a.Cout + 31) / 32 * 32;
   a.mode = EPI_GENERIC;
   if (a.Cout % 32 == 0) {
@@ -270,54 +86,99 @@ int run_x3(ConvArgs a, hipStream_t st) {
       else if (!a.act && a.skip) a.mode = EPI_DGRAD_ADD;
     }
   }
+  // vector width of the global accesses: rows of W floats must keep VW-float alignment
+  auto aligned = [](const void* q, size_t b) { return q == nullptr || ((uintptr_t)q % b) == 0; };
+  int VW = 1;
+  if (a.W % 4 == 0 && aligned(a.x, 16) && aligned(a.y_full, 16) && aligned(a.y_out, 16) && aligned(a.skip, 16) &&
+      aligned(a.act, 16)) VW = 4;
+  else if (a.W % 2 == 0 && aligned(a.x, 8)) VW = 2;
   const int rows_total = a.VR - 1;
-  int bestNT = 0, bestMT = 0, bestR = 0; long bestT = 0;
-  int forceMT = 0, forceNT = 0;
-  if (const char* e = getenv("FDET_CONV_TILE")) sscanf(e, "%d,%d", &forceMT, &forceNT);
-  for (int MT = (a.CoP % 64 == 0) ? 2 : 1; MT >= 1; --MT)
-    for (int NT = 4; NT >= 1; NT >>= 1) {
-      if (forceMT && (MT != forceMT || NT != forceNT)) continue;
-      const int cap = 4 * NT * 32;
-      if (a.WP > cap) continue;
-      int R = cap / a.WP;
+  const int ncu = num_cus();
+  const int MT = (a.CoP % 64 == 0) ? 2 : 1;
+  const int ncob = a.CoP / (MT * 32);
+  // Tile choice: (NW waves, NT tiles per wave): positions per workgroup = 32*NW*NT; column segmentation.
+  // measured on MI355X (64 channels, 60x60 / 30x30 / 15x15): microseconds per 128 positions of a tile
+  static const int cfgs2[][2] = {{8, 1}, {4, 4}, {8, 2}};     // must match fdet_conv3x3_x3_configs.h
+  static const double kcfg2[] = {8.1, 8.5, 10.8};
+  static const int cfgs1[][2] = {{8, 1}, {8, 2}};
+  static const double kcfg1[] = {8.1, 10.8};
+  const int (*cfgs)[2] = MT == 2 ? cfgs2 : cfgs1;
+  const double* kcfg = MT == 2 ? kcfg2 : kcfg1;
+  const int ncfg = MT == 2 ? 3 : 2;
+  int bestNW = 0, bestNT = 0, bestR = 0, bestCW = 0, bestNSEG = 0, bestWP = 0; double bestT = 0;
+  int forceNW = 0, forceNT = 0;
+  if (const char* e = getenv("FDET_CONV_TILE")) sscanf(e, "%d,%d", &forceNW, &forceNT);
+  for (int ci = 0; ci < ncfg; ++ci) {
+    const int NW = cfgs[ci][0], NT = cfgs[ci][1], nthr = NW * 64;
+    if (forceNT && (NT != forceNT || NW != forceNW)) continue;
+    const int cap = NW * NT * 32;
+    // widest segment whose double-buffered tile fits LDS
+    for (int NSEG = 1; NSEG <= 64; ++NSEG) {
+      int CW = (a.W + NSEG - 1) / NSEG;
+      if (NSEG > 1) CW = (CW + 3) / 4 * 4;
+      if (NSEG > 1 && (NSEG - 1) * CW >= a.W) continue;
+      const int WP = ((NSEG > 1 ? CW + 2 : a.W + 1) + 3) / 4 * 4;
+      if (WP > cap) continue;
+      int R = cap / WP;
       if (R > rows_total) R = rows_total;
-      if (2 * (R + 2) * a.W > NBS * NTHR) continue;
-      const int PT = cap + 2 * a.WP + 3;
-      const size_t lds = (size_t)2 * (2 * 9 * 2 * MT * 32 + 4 * PT) * 16;
+      const int PT = cap + 2 * WP + 3;
+      const size_t lds = ((size_t)2 * (2 * 9 * 2 * MT * 32 + 4 * PT) + nthr) * 16;
       if (lds > 160 * 1024) continue;
+      if (NSEG > 1 && VW != 4) continue;                              // segmented rows: W % 4 == 0 only
+      if (2 * (R + 2) * (CW / VW) > nbs_of(NW, NT, VW) * nthr) continue;
+      if (NSEG > 1 && 4 * (R + 2) > nthr) continue;
       const long nb = (rows_total + R - 1) / R;
-      const long waves = nb * (a.CoP / (MT * 32)) * 4;
-      // one workgroup per CU: rounds of 1024 waves; fixed per-workgroup cost ~ 2 tile-jobs
-      const long t = ((waves + 1023) / 1024) * (MT * NT + 2);
-      if (bestNT == 0 || t < bestT) { bestNT = NT; bestMT = MT; bestR = R; bestT = t; }
+      const long tiles = nb * NSEG * ncob;
+      const long rounds = (tiles + ncu - 1) / ncu;
+      // per tile: MFMA work ~ cap, plus an un-overlapped share; halo rows/columns are re-read
+      const double t = rounds * (cap / 128.0) * kcfg[ci] * (1.0 + 0.1 * (2.0 / R + (NSEG > 1 ? 2.0 / CW : 0.0)));
+      if (bestNT == 0 || t < bestT) { bestNW = NW; bestNT = NT; bestR = R; bestCW = CW; bestNSEG = NSEG; bestWP = WP; bestT = t; }
+      break;                                                          // first NSEG that fits is the widest
     }
+  }
   if (bestNT == 0) return fail(FDET_EINVAL, "conv3x3_bf16x3: no tiling for W=%d H=%d", a.W, a.H);
-  const int NT = bestNT, MT = bestMT;
-  const int cap = 4 * NT * 32;
+  const int NT = bestNT, NW = bestNW;
+  const int cap = NW * NT * 32;
   a.R = bestR;
+  a.WP = bestWP;
   a.nbands = (rows_total + a.R - 1) / a.R;
   a.magic_h1 = magic_of(a.H + 1);
   X3Args p;
   p.PT = cap + 2 * a.WP + 3;
-  p.p_in = (a.R + 2) * a.W;
-  p.magic_w = magic_of(a.W);
+  p.CW = bestCW;
+  p.NSEG = bestNSEG;
+  p.ncob = ncob;
+  p.ntiles = a.nbands * bestNSEG * ncob;
+  p.WV = bestCW / VW;
+  p.items_half = (a.R + 2) * p.WV;
+  p.magic_wv = magic_of(p.WV);
+  p.magic_wp = magic_of(a.WP);
   const size_t units = (size_t)(a.Cin / 16) * 9 * 2 * a.CoP;       // per hi / lo half
   p.a_hi = reinterpret_cast<const bf16x8*>(a.wpk);
   p.a_lo = p.a_hi + units;
   p.c = a;
-  const size_t lds = (size_t)2 * (2 * 9 * 2 * MT * 32 + 4 * p.PT) * 16;
-  dim3 grid(a.nbands, a.CoP / (MT * 32));
-  if (MT == 2) {
-    if (NT == 4) return launch_x3<2, 4>(p, lds, grid, st);
-    if (NT == 2) return launch_x3<2, 2>(p, lds, grid, st);
-    return launch_x3<2, 1>(p, lds, grid, st);
+  const size_t lds = ((size_t)2 * (2 * 9 * 2 * MT * 32 + 4 * p.PT) + NW * 64) * 16;
+  const int grid = p.ntiles < ncu ? p.ntiles : ncu;
+  p.c.stagger = 0;
+  if (NW == 4 && p.ntiles >= 4 * grid) p.c.stagger = cap / 128 * 9000;   // ~ one tile time, in shader clocks
+  if (const char* e = getenv("FDET_CONV_STAGGER")) p.c.stagger = atoi(e);
+  const bool seg = bestNSEG > 1;
+  p.stamps = g_probe_stamps;
+  switch (a.mode) {
+    case EPI_FWD_FULL: return fdet_x3_launch_m1(p, MT, NW, NT, VW, seg, lds, grid, st);
+    case EPI_FWD_BOTH: return fdet_x3_launch_m2(p, MT, NW, NT, VW, seg, lds, grid, st);
+    case EPI_FWD_OUT: return fdet_x3_launch_m3(p, MT, NW, NT, VW, seg, lds, grid, st);
+    case EPI_DGRAD_ACT: return fdet_x3_launch_m4(p, MT, NW, NT, VW, seg, lds, grid, st);
+    case EPI_DGRAD_ADD: return fdet_x3_launch_m5(p, MT, NW, NT, VW, seg, lds, grid, st);
+    default: return fdet_x3_launch_m0(p, MT, NW, NT, VW, seg, lds, grid, st);
   }
-  if (NT == 4) return launch_x3<1, 4>(p, lds, grid, st);
-  if (NT == 2) return launch_x3<1, 2>(p, lds, grid, st);
-  return launch_x3<1, 1>(p, lds, grid, st);
 }
 
 }  // namespace
+
+#ifdef FDET_X3_STAMPS
+extern "C" int fdet_x3_probe_set(long long* buf) { g_probe_stamps = buf; return 0; }
+#endif
 
 extern "C" int fdet_pack_conv3x3_weights_bf16x3(const float* w, int Cout, int Cin, void* wpk_fwd, void* wpk_bwd,
                                                 void* stream) {

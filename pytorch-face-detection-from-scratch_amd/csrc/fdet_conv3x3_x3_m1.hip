@@ -1,0 +1,5 @@
+// bf16x3 3x3 conv kernels, epilogue mode EPI_FWD_FULL (see fdet_conv3x3_x3_kernel.inc)
+#define X3_MODE EPI_FWD_FULL
+#define X3_MODE_ID 1
+#include "fdet_conv3x3_x3_configs.h"
+#include "fdet_conv3x3_x3_kernel.inc"

@@ -1,0 +1,268 @@
+// bf16x3 3x3 conv forward / data gradient, small-tile variant: one band of <= 256 positions per
+// workgroup, ONE LDS buffer (<= 80 KB) and <= 256 registers, so two workgroups share a CU and one's
+// staging / epilogue runs beside the other's MFMAs.  Fastest for rows of <= 64 columns (the
+// PoolResnet resolutions); anything it has no tiling for goes to the general persistent kernel
+// (fdet_conv3x3_x3_kernel.inc).  Same arithmetic, LDS layout and epilogue fusion modes as described there.
+#include "fdet_conv_common.h"
+#include <algorithm>
+
+using namespace fdet;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int CK16 = 16;     // input channels per chunk (= MFMA K)
+// B staging slots per thread (8 fp32 loads each): 2*(R+2)*W <= nbs*NTHR is checked on the host
+__host__ __device__ constexpr int nbs_of(int nt) { return nt == 4 ? 5 : 3; }
+
+struct X3SbArgs {
+  ConvArgs c;                // x, bias, epilogue pointers, geometry (WP, R, VR, nbands, mode ...)
+  const bf16x8* a_hi;        // [Cin/16][9][2][CoP] x 8 bf16
+  const bf16x8* a_lo;
+  int PT;                    // positions per B array (cap + 2*WP + 3)
+  int p_in;                  // (R+2)*W staged positions per k-half
+  unsigned magic_w;
+};
+
+__device__ __forceinline__ void split8(const float (&f)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)f[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(f[j] - (float)h);
+  }
+}
+
+// Single LDS buffer (<= 80 KB, <= 256 registers): two workgroups share a CU, and one's staging /
+// epilogue runs beside the other's MFMAs.
+template <int MT, int NT>
+__global__ void __launch_bounds__(NTHR, 2)
+k_conv3x3_x3_sb(const X3SbArgs p) {
+  constexpr int NBS = nbs_of(NT);
+  const ConvArgs& a = p.c;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MB = MT * 32;
+  constexpr int A_UNITS = 9 * 2 * MB;                 // 16-byte units per A array per chunk
+  constexpr int NA = (2 * A_UNITS + NTHR - 1) / NTHR; // hi and lo
+  const int PT = p.PT, WP = a.WP;
+  const int buf_units = 2 * A_UNITS + 4 * PT;         // 16-byte units per buffer
+  bf16x8* lds = reinterpret_cast<bf16x8*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int band = blockIdx.x, mb = blockIdx.y;
+  const int v0 = band * a.R;
+  const int H1 = a.H + 1;
+  const size_t HW = (size_t)a.H * a.W;
+
+  {  // zero both buffers: halo positions of the B arrays are never written again
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    for (int t = tid; t < buf_units; t += NTHR) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- B staging geometry (chunk invariant): slot -> (k-half, tile row, column)
+  int b_src[NBS], b_dst[NBS];                         // src: element offset for channel 8h of chunk 0 (-1: skip)
+#pragma unroll
+  for (int s = 0; s < NBS; ++s) {
+    const int it = s * NTHR + tid;
+    b_src[s] = -1; b_dst[s] = 0;
+    if (it < 2 * p.p_in) {
+      const int h = it >= p.p_in ? 1 : 0;
+      const int pp = it - h * p.p_in;
+      const int tr = fdiv(pp, p.magic_w), ix = pp - tr * a.W;
+      const int v = v0 - 1 + tr;
+      if (v >= 0 && v < a.VR) {
+        const int n = fdiv(v, a.magic_h1), yy = v - n * H1 - 1;
+        if (yy >= 0) {
+          b_src[s] = ((n * a.Cin + 8 * h) * a.H + yy) * a.W + ix;
+          b_dst[s] = h * PT + tr * WP + 1 + ix;       // unit index inside the hi array pair; lo = +2*PT
+        }
+      }
+    }
+  }
+  const int a_chunk_units = 9 * 2 * a.CoP;            // units per chunk per array in HBM
+  bf16x8 pa[NA];
+  float pb[NBS][8];
+#define X3_ISSUE_LOADS(C16)                                                                        \
+  {                                                                                                \
+    _Pragma("unroll") for (int s_ = 0; s_ < NA; ++s_) {                                            \
+      const int u_ = min(tid + s_ * NTHR, 2 * A_UNITS - 1);                                        \
+      const int lo_ = u_ >= A_UNITS ? 1 : 0;                                                       \
+      const int r_ = u_ - lo_ * A_UNITS;                                                           \
+      const int th_ = r_ / MB, co_ = r_ - th_ * MB;                                                \
+      const bf16x8* src_ = (lo_ ? p.a_lo : p.a_hi) + (size_t)(C16) * a_chunk_units + th_ * a.CoP + mb * MB + co_; \
+      pa[s_] = *src_;                                                                              \
+    }                                                                                              \
+    const float* xs_ = a.x + (size_t)(C16) * CK16 * HW;                                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < NBS; ++s_) {                                           \
+      const float* q_ = xs_ + max(b_src[s_], 0);                                                   \
+      _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) pb[s_][j_] = q_[j_ * HW];                   \
+    }                                                                                              \
+  }
+#define X3_WRITE_LDS(BUF)                                                                          \
+  {                                                                                                \
+    bf16x8* buf_ = (BUF);                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < NA; ++s_) {                                            \
+      const int u_ = tid + s_ * NTHR;                                                              \
+      if (u_ < 2 * A_UNITS) buf_[u_] = pa[s_];                                                     \
+    }                                                                                              \
+    bf16x8* B_ = buf_ + 2 * A_UNITS;                                                               \
+    _Pragma("unroll") for (int s_ = 0; s_ < NBS; ++s_) {                                           \
+      if (b_src[s_] >= 0) {                                                                        \
+        bf16x8 hi_, lo_;                                                                           \
+        split8(pb[s_], hi_, lo_);                                                                  \
+        B_[b_dst[s_]] = hi_;                                                                       \
+        B_[b_dst[s_] + 2 * PT] = lo_;                                                              \
+      }                                                                                            \
+    }                                                                                              \
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  int tapoff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tapoff[t] = (t / 3) * WP + (t % 3);
+
+  const int qwave = wid * NT * 32;
+  const int a_off = half * MB + l31;                           // + tap*2*MB + m*32 ; lo: + A_UNITS
+  const int b_off = 2 * A_UNITS + half * PT + qwave + l31;     // + tapoff + n*32   ; lo: + 2*PT
+
+  X3_ISSUE_LOADS(0)
+  __syncthreads();                       // zero fill complete
+
+  const int nch = a.Cin / CK16;
+  for (int c = 0; c < nch; ++c) {
+    const bf16x8* buf = lds;
+    if (c > 0) __syncthreads();          // every wave is done reading chunk c-1
+    X3_WRITE_LDS(lds)
+    __syncthreads();
+    if (c + 1 < nch) X3_ISSUE_LOADS(c + 1)
+    const bf16x8* Aw = buf + a_off;
+    const bf16x8* Bw = buf + b_off;
+    // one fragment set: while this wave waits for its LDS reads the partner wave of the other
+    // workgroup owns the matrix pipe
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) ah[m] = Aw[t * 2 * MB + m * 32];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bl[n] = Bw[2 * PT + tapoff[t] + n * 32];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) al[m] = Aw[A_UNITS + t * 2 * MB + m * 32];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bh[n] = Bw[tapoff[t] + n * 32];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue (shared with the fp32 kernel: same accumulator layout)
+  const int qlimit = a.R * WP;
+  bool okn[NT];
+  size_t basen[NT];
+  int imgn[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int q = qwave + n * 32 + l31;
+    const int tr = q / WP, ox = q - tr * WP;
+    const int v = v0 + tr;
+    const int img = v / H1, oy = v - img * H1 - 1;
+    okn[n] = (q < qlimit) && (ox < a.W) && (v < a.VR) && (oy >= 0);
+    basen[n] = ((size_t)img * a.Cout * a.H + oy) * a.W + ox;
+    imgn[n] = img;
+  }
+  const int cob0 = mb * MB + 4 * half;
+  switch (a.mode) {
+    case EPI_FWD_FULL: epilogue<MT, NT, EPI_FWD_FULL>(a, acc, okn, basen, imgn, cob0, HW); break;
+    case EPI_FWD_BOTH: epilogue<MT, NT, EPI_FWD_BOTH>(a, acc, okn, basen, imgn, cob0, HW); break;
+    case EPI_FWD_OUT: epilogue<MT, NT, EPI_FWD_OUT>(a, acc, okn, basen, imgn, cob0, HW); break;
+    case EPI_DGRAD_ACT: epilogue<MT, NT, EPI_DGRAD_ACT>(a, acc, okn, basen, imgn, cob0, HW); break;
+    case EPI_DGRAD_ADD: epilogue<MT, NT, EPI_DGRAD_ADD>(a, acc, okn, basen, imgn, cob0, HW); break;
+    default: epilogue<MT, NT, EPI_GENERIC>(a, acc, okn, basen, imgn, cob0, HW); break;
+  }
+}
+
+template <int MT, int NT>
+int launch_sb(const X3SbArgs& p, size_t lds, dim3 grid, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)k_conv3x3_x3_sb<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_conv3x3_x3_sb<MT, NT>), grid, dim3(NTHR), lds, st, p);
+  return check_launch("fdet_conv3x3_bf16x3(sb)");
+}
+
+}  // namespace
+
+// Returns 1 when this kernel family has no tiling for the shape (the caller then uses the general
+// persistent kernel), else the launch status.  `a` arrives with N/Cin/Cout/H/W, pointers, dgrad, slope set.
+int fdet_x3_sb_run(ConvArgs a, hipStream_t st) {
+  a.WP = a.W + 1;
+  a.VR = a.N * (a.H + 1) + 1;
+  if (a.VR >= (1 << 20) || (size_t)a.N * std::max(a.Cin, a.Cout) * a.H * a.W >= (size_t)1 << 31) return 1;
+  a.CoP = (a.Cout + 31) / 32 * 32;
+  a.mode = EPI_GENERIC;
+  if (a.Cout % 32 == 0) {
+    if (!a.dgrad && a.bias) {
+      if (a.y_full && !a.y_out) a.mode = EPI_FWD_FULL;
+      else if (a.y_full && a.y_out && a.skip && a.scale) a.mode = EPI_FWD_BOTH;
+      else if (!a.y_full && a.y_out && a.skip && !a.scale) a.mode = EPI_FWD_OUT;
+    } else if (a.dgrad) {
+      if (a.act && !a.skip) a.mode = EPI_DGRAD_ACT;
+      else if (!a.act && a.skip) a.mode = EPI_DGRAD_ADD;
+    }
+  }
+  const int rows_total = a.VR - 1;
+  int bestNT = 0, bestMT = 0, bestR = 0; double bestT = 0;
+  for (int MT = (a.CoP % 64 == 0) ? 2 : 1; MT >= 1; --MT)
+    for (int NT = 2; NT >= 1; NT >>= 1) {
+      const int cap = 4 * NT * 32;
+      if (a.WP > cap) continue;
+      int R = cap / a.WP;
+      if (R > rows_total) R = rows_total;
+      if (2 * (R + 2) * a.W > nbs_of(NT) * NTHR) continue;
+      const int PT = cap + 2 * a.WP + 3;
+      const size_t lds = (size_t)(2 * 9 * 2 * MT * 32 + 4 * PT) * 16;
+      if (lds > 80 * 1024) continue;
+      const long nb = (rows_total + R - 1) / R;
+      const long wgs = nb * (a.CoP / (MT * 32));
+      const long rounds = (wgs + 511) / 512;
+      const double t = rounds * (2.0 * MT * NT + 0.6) * (1.0 + 0.25 * 2.0 / R);
+      if (bestNT == 0 || t < bestT) { bestNT = NT; bestMT = MT; bestR = R; bestT = t; }
+    }
+  if (bestNT == 0) return 1;
+  const int NT = bestNT, MT = bestMT;
+  const int cap = 4 * NT * 32;
+  a.R = bestR;
+  a.nbands = (rows_total + a.R - 1) / a.R;
+  a.magic_h1 = magic_of(a.H + 1);
+  X3SbArgs p;
+  p.PT = cap + 2 * a.WP + 3;
+  p.p_in = (a.R + 2) * a.W;
+  p.magic_w = magic_of(a.W);
+  const size_t units = (size_t)(a.Cin / 16) * 9 * 2 * a.CoP;       // per hi / lo half
+  p.a_hi = reinterpret_cast<const bf16x8*>(a.wpk);
+  p.a_lo = p.a_hi + units;
+  p.c = a;
+  const size_t lds = (size_t)(2 * 9 * 2 * MT * 32 + 4 * p.PT) * 16;
+  dim3 grid(a.nbands, a.CoP / (MT * 32));
+  if (MT == 2 && NT == 2) return launch_sb<2, 2>(p, lds, grid, st);
+  if (MT == 2 && NT == 1) return launch_sb<2, 1>(p, lds, grid, st);
+  if (MT == 1 && NT == 2) return launch_sb<1, 2>(p, lds, grid, st);
+  return launch_sb<1, 1>(p, lds, grid, st);
+}

@@ -8,13 +8,8 @@ using namespace fdet;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-namespace {
-
-constexpr int CK = 8;        // input channels per LDS chunk
-constexpr int NTHR = 256;    // 4 waves
-// B prefetch slots per thread (vector items of VW floats)
-__host__ __device__ constexpr int nbmax(int vw) { return vw == 4 ? 6 : (vw == 2 ? 8 : 10); }
-
+namespace fdet {
+// (named namespace: the bf16x3 kernels pass this block between translation units)
 struct ConvArgs {
   const float* x;        // [N,Cin,H,W]
   const float* wpk;      // [Cin*9][CoP]
@@ -33,6 +28,15 @@ struct ConvArgs {
   unsigned magic_rows;   // ceil(2^32/(R+2))
   float slope;
 };
+}  // namespace fdet
+
+namespace {
+
+constexpr int CK = 8;        // input channels per LDS chunk
+constexpr int NTHR = 256;    // 4 waves
+// B prefetch slots per thread (vector items of VW floats)
+__host__ __device__ constexpr int nbmax(int vw) { return vw == 4 ? 6 : (vw == 2 ? 8 : 10); }
+
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -41,6 +41,7 @@ struct WgX3Args {
   float* ws;               // [L][nslab][9][CoP][CiP]
   float* wsb;              // [L][nslab][CoP]
   int N, Cin, Cout, CoP, CiP, H, W, P, R, VR, QZ, PX, Kext, nbands, L, ncob;
+  int NSEG, CW;            // column segments per row (wide images), columns per segment
   unsigned magic_h1;
 };
 
@@ -99,8 +100,12 @@ __device__ __forceinline__ bf16x8 shift_chunks(const bf16x8& c_lo, const bf16x8&
   return __builtin_bit_cast(bf16x8, o);
 }
 
-// MTC co tiles per workgroup (64 or 32 output channels), 32 input channels per workgroup
-template <int MTC, int VW>
+// MTC co tiles per workgroup (64 or 32 output channels), 32 input channels per workgroup.
+// SEG: rows wider than 16 vector lanes are cut into column segments of CW <= 56 columns.  The sum
+// over (dz position, x position) pairs is partitioned by dz ROW (band) and x COLUMN (segment), so a
+// segment stages its own x columns and dz columns [x0-1, x0+CW] -- lanes 14 / 15 of each 16-lane row
+// group fetch the two dz halo columns.
+template <int MTC, int VW, bool SEG>
 __global__ void __launch_bounds__(NTHR, 1)
 k_wgrad3x3_x3(const WgX3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -143,11 +148,11 @@ k_wgrad3x3_x3(const WgX3Args a) {
   const bf16x8* xrow_l = reinterpret_cast<const bf16x8*>(Xl + l31 * a.PX) + half;
   const int p8 = P / 8;                               // row pitch in 16-byte chunks
 
-  // staging geometry: 16 lanes per row (W/VW <= 16), 16 channels per pass
-  const int wv = W / VW;
+  // staging geometry: 16 lanes per row (W/VW <= 16, or one segment of <= 14 lanes), 16 channels per pass
   const int xv = tid & 15;
   const int chl = tid >> 4;
-  const bool lane_ok = xv < wv;
+  int x0 = 0, wcur = W;                               // current segment
+  bool lane_ok = xv < W / VW;
   const int co0 = cob * MB, ci0 = cib * 32;
   const int HW = a.H * W;
   float bpart[ZCH];
@@ -155,8 +160,19 @@ k_wgrad3x3_x3(const WgX3Args a) {
   for (int c = 0; c < ZCH; ++c) bpart[c] = 0.f;
 
   VT pz[ZCH][RZ], px[XCH][RX];
-#define X3_WG_LOAD(V0)                                                                            \
+  float pzh[SEG ? ZCH : 1][SEG ? RZ : 1];             // dz halo column (lane 14: left, lane 15: right)
+#define X3_WG_LOAD(ITEM)                                                                          \
   {                                                                                               \
+    int V0;                                                                                       \
+    if (SEG) {                                                                                    \
+      const int band_ = (ITEM) / a.NSEG, seg_ = (ITEM) - band_ * a.NSEG;                          \
+      V0 = band_ * R; x0 = seg_ * a.CW; wcur = min(a.CW, W - x0);                                 \
+      lane_ok = xv < wcur / VW;                                                                   \
+    } else {                                                                                      \
+      V0 = (ITEM) * R;                                                                            \
+    }                                                                                             \
+    const int hcol_ = xv == 14 ? x0 - 1 : x0 + wcur;                                              \
+    const bool hok_ = SEG && xv >= 14 && hcol_ >= 0 && hcol_ < W;                                 \
     _Pragma("unroll") for (int r_ = 0; r_ < RZ; ++r_) {                                           \
       const int v = (V0) + r_;                                                                    \
       const int n = fdiv(v, a.magic_h1), yy = v - n * H1 - 1;                                     \
@@ -165,7 +181,8 @@ k_wgrad3x3_x3(const WgX3Args a) {
       _Pragma("unroll") for (int c_ = 0; c_ < ZCH; ++c_) {                                        \
         const int ch = co0 + c_ * 16 + chl;                                                       \
         pz[c_][r_] = (rok && lane_ok && ch < a.Cout)                                              \
-                         ? *reinterpret_cast<const VT*>(rowp + (size_t)ch * HW + xv * VW) : vzero<VW>(); \
+                         ? *reinterpret_cast<const VT*>(rowp + (size_t)ch * HW + x0 + xv * VW) : vzero<VW>(); \
+        if (SEG) pzh[c_][r_] = (rok && hok_ && ch < a.Cout) ? rowp[(size_t)ch * HW + hcol_] : 0.f; \
       }                                                                                           \
     }                                                                                             \
     _Pragma("unroll") for (int r_ = 0; r_ < RX; ++r_) {                                           \
@@ -176,13 +193,13 @@ k_wgrad3x3_x3(const WgX3Args a) {
       _Pragma("unroll") for (int c_ = 0; c_ < XCH; ++c_) {                                        \
         const int ch = ci0 + c_ * 16 + chl;                                                       \
         px[c_][r_] = (rok && lane_ok && ch < a.Cin)                                               \
-                         ? *reinterpret_cast<const VT*>(rowp + (size_t)ch * HW + xv * VW) : vzero<VW>(); \
+                         ? *reinterpret_cast<const VT*>(rowp + (size_t)ch * HW + x0 + xv * VW) : vzero<VW>(); \
       }                                                                                           \
     }                                                                                             \
   }
 #define X3_WG_STORE()                                                                             \
   {                                                                                               \
-    if (lane_ok) {                                                                                \
+    if (SEG ? xv < 14 : lane_ok) {                                                                \
       _Pragma("unroll") for (int r_ = 0; r_ < RZ; ++r_) {                                         \
         if (r_ < R) {                                                                             \
           _Pragma("unroll") for (int c_ = 0; c_ < ZCH; ++c_) {                                    \
@@ -201,16 +218,30 @@ k_wgrad3x3_x3(const WgX3Args a) {
         }                                                                                         \
       }                                                                                           \
     }                                                                                             \
+    /* halo columns last: same wave, LDS writes in program order, so they win over the zero fill */ \
+    if (SEG && xv >= 14) {                                                                        \
+      _Pragma("unroll") for (int r_ = 0; r_ < RZ; ++r_) {                                         \
+        if (r_ < R) {                                                                             \
+          _Pragma("unroll") for (int c_ = 0; c_ < ZCH; ++c_) {                                    \
+            const int row_ = (c_ * 16 + chl) * a.QZ;                                              \
+            put_split<1>(Zh + row_, Zl + row_, ZP + r_ * P + (xv == 14 ? -1 : s_wcur), pzh[c_][r_]); \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+    }                                                                                             \
   }
 
+  // work items: bands (x column segments)
+  const int nitems = a.nbands * (SEG ? a.NSEG : 1);
   int band = blockIdx.x;
-  if (band < a.nbands) X3_WG_LOAD(band * R)
-  for (; band < a.nbands; band += gridDim.x) {
+  int s_wcur = W;                    // segment width of the tile held in the prefetch registers
+  if (band < nitems) { X3_WG_LOAD(band) s_wcur = wcur; }
+  for (; band < nitems; band += gridDim.x) {
     __syncthreads();                 // previous band's MFMAs done (first pass: zero fill done)
     X3_WG_STORE()
     __syncthreads();
     const int nb = band + gridDim.x;
-    if (nb < a.nbands) X3_WG_LOAD(nb * R)
+    if (nb < nitems) { X3_WG_LOAD(nb) s_wcur = wcur; }
 #pragma unroll 1
     for (int ks = ks0; ks < ks1; ++ks) {
       // dz chunks at elements e, e+8, e+16 (e = 16*ks + 8*half); kx=1 <- [e+8,e+16)
@@ -322,17 +353,19 @@ k_wgx3_reduce(const float* __restrict__ ws_all, const float* __restrict__ wsb_al
 
 unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
-struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw; size_t lds, ws_floats; bool ok; };
+struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw, NSEG, CW; size_t lds, ws_floats; bool ok; };
 
 WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   WgX3Plan p{};
-  p.P = (W + 1 + 7) / 8 * 8;
+  p.vw = (W % 4 == 0) ? 4 : (W % 2 == 0 ? 2 : 1);
+  p.NSEG = 1; p.CW = W;
+  if (W / p.vw > 16 && p.vw == 4) { p.CW = 56; p.NSEG = (W + 55) / 56; }     // column segments (14 vector lanes)
+  p.P = p.NSEG > 1 ? 64 : (W + 1 + 7) / 8 * 8;
   p.VR = N * (H + 1) + 1;
   p.CoP = (Cout + 31) / 32 * 32;
   p.CiP = (Cin + 31) / 32 * 32;
   p.MTC = (p.CoP % 64 == 0) ? 2 : 1;
-  p.vw = (W % 4 == 0) ? 4 : (W % 2 == 0 ? 2 : 1);
-  const int wv = W / p.vw;
+  const int wv = p.CW / p.vw;
   p.ok = wv <= 16 && p.VR < (1 << 20) && (size_t)N * std::max(Cin, Cout) * H * W < ((size_t)1 << 31);
   const int rows_total = p.VR - 1;
   const int zch = p.MTC * 2;
@@ -345,10 +378,10 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
     int PX = Kext + 2 * p.P + 8; if (((PX / 8) & 1) == 0) PX += 8;
     const size_t bytes = ((size_t)p.MTC * 32 * QZ + 32 * (size_t)PX) * 4;
     if (bytes > 150 * 1024) break;
-    const long nb = (rows_total + r - 1) / r;
+    const long nb = (long)((rows_total + r - 1) / r) * p.NSEG;
     const long slots = std::max(1, 256 / ((p.CiP / 32) * (p.CoP / (p.MTC * 32)) * L));   // workgroups along x so that the grid ~ 256
     const long blk = std::max(1L, std::min(nb, slots));
-    const double mfma = (double)(((nb + blk - 1) / blk) * blk * Kext) / ((double)rows_total * p.P);
+    const double mfma = (double)(((nb + blk - 1) / blk) * blk * Kext) / ((double)rows_total * p.P * p.NSEG);
     const double cost = mfma * (0.7 + 0.3 * (double)(r + 2) / r);
     if (cost <= bestC * 1.0001) { bestC = cost; bestR = r; }
   }
@@ -360,7 +393,7 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   p.PX = p.Kext + 2 * p.P + 8; if (((p.PX / 8) & 1) == 0) p.PX += 8;
   p.nbands = (rows_total + p.R - 1) / p.R;
   const long slots = std::max(1, 256 / ((p.CiP / 32) * (p.CoP / (p.MTC * 32)) * L));
-  p.nblk = (int)std::max(1L, std::min((long)p.nbands, slots));
+  p.nblk = (int)std::max(1L, std::min((long)p.nbands * p.NSEG, slots));
   p.lds = ((size_t)p.MTC * 32 * p.QZ + 32 * (size_t)p.PX) * 4;
   p.lds = std::max(p.lds, (size_t)p.MTC * 144 * 64 * 4);
   p.ws_floats = (size_t)L * ((size_t)p.nblk * 9 * p.CoP * p.CiP + (size_t)p.nblk * p.CoP);
@@ -373,9 +406,10 @@ void launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) 
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
     hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds, st, a);
   };
-  if (p.vw == 4) go(k_wgrad3x3_x3<MTC, 4>);
-  else if (p.vw == 2) go(k_wgrad3x3_x3<MTC, 2>);
-  else go(k_wgrad3x3_x3<MTC, 1>);
+  if (p.NSEG > 1) go(k_wgrad3x3_x3<MTC, 4, true>);
+  else if (p.vw == 4) go(k_wgrad3x3_x3<MTC, 4, false>);
+  else if (p.vw == 2) go(k_wgrad3x3_x3<MTC, 2, false>);
+  else go(k_wgrad3x3_x3<MTC, 1, false>);
 }
 
 }  // namespace
@@ -383,7 +417,7 @@ void launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) 
 static int run_wg_x3(const float* const* xs, const float* const* dzs, float* const* dWs, float* const* dbs, int L,
                      void* ws, size_t ws_bytes, int N, int Cin, int Cout, int H, int W, hipStream_t st) {
   const WgX3Plan p = plan_x3(N, Cin, Cout, H, W, L);
-  FDET_REQUIRE(p.ok, "conv3x3_wgrad_bf16x3: no tiling for N=%d H=%d W=%d (row must fit 16 vector lanes)", N, H, W);
+  FDET_REQUIRE(p.ok, "conv3x3_wgrad_bf16x3: no tiling for N=%d H=%d W=%d (rows wider than 64 need W %% 4 == 0)", N, H, W);
   if (ws_bytes < p.ws_floats * 4)
     return fail(FDET_EWORKSPACE, "conv3x3_wgrad_bf16x3: workspace %zu < %zu bytes", ws_bytes, p.ws_floats * 4);
   WgX3Args a{};
@@ -392,7 +426,7 @@ static int run_wg_x3(const float* const* xs, const float* const* dzs, float* con
   a.ws = (float*)ws; a.wsb = (float*)ws + (size_t)L * p.nblk * 9 * p.CoP * p.CiP;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.CoP = p.CoP; a.CiP = p.CiP; a.H = H; a.W = W; a.P = p.P; a.R = p.R;
   a.VR = p.VR; a.QZ = p.QZ; a.PX = p.PX; a.Kext = p.Kext; a.nbands = p.nbands; a.magic_h1 = magic_of(H + 1);
-  a.L = L; a.ncob = p.CoP / (p.MTC * 32);
+  a.L = L; a.ncob = p.CoP / (p.MTC * 32); a.NSEG = p.NSEG; a.CW = p.CW;
   dim3 grid(p.nblk, p.CiP / 32, a.ncob * L);
   if (p.MTC == 2) launch_x3<2>(a, p, grid, st); else launch_x3<1>(a, p, grid, st);
   if (int rc = check_launch("fdet_conv3x3_wgrad_bf16x3")) return rc;

@@ -134,6 +134,29 @@ def u8_to_f32_norm(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def resize_bilinear_norm(x: torch.Tensor, size: Tuple[int, int], divisor: float = 255.0) -> torch.Tensor:
+    """`Resize(size)(x) / 255.0` on the device (torchvision 0.11.2 tensor semantics: bilinear,
+    align_corners=False, no antialias).  uint8 input goes through the uint8 round trip (round half
+    even) before the division; float input is interpolated and divided.  (N,C,H,W) or (C,H,W)."""
+    if x.dim() == 3:
+        x = x.unsqueeze(0)
+    if x.dim() != 4:
+        raise ValueError(f"resize_bilinear_norm: expected (N,C,H,W) or (C,H,W), got {tuple(x.shape)}")
+    x = x.contiguous()
+    Nn, C, Hs, Ws = x.shape
+    Hd, Wd = int(size[0]), int(size[1])
+    out = torch.empty(Nn, C, Hd, Wd, dtype=F32, device=x.device)
+    if x.dtype == torch.uint8:
+        if divisor != 255.0:
+            raise ValueError("resize_bilinear_norm: the uint8 path always divides by 255")
+        check(lib().fdet_resize_bilinear_u8_norm(ptr(x, torch.uint8), ptr(out), Nn, C, Hs, Ws, Hd, Wd, stream()),
+              "fdet_resize_bilinear_u8_norm")
+    else:
+        check(lib().fdet_resize_bilinear_f32_norm(ptr(_f32(x)), ptr(out), Nn, C, Hs, Ws, Hd, Wd, float(divisor), stream()),
+              "fdet_resize_bilinear_f32_norm")
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # optimiser / dropout
 # ------------------------------------------------------------------------------------------
@@ -259,6 +282,65 @@ def conv3x3_wgrad_batched(xs, dzs, dWs, dbs, ws):
     hdW, hdb = arr(*[ptr(t) for t in dWs]), arr(*[ptr(t) for t in dbs])
     check(lib().fdet_conv3x3_wgrad_bf16x3_batched(hx, hdz, hdW, hdb, L, ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
                                                   Nn, cin, cout, H, W, stream()), "fdet_conv3x3_wgrad_bf16x3_batched")
+
+
+def _ptr_array(ts, dtype=F32):
+    """HOST array of device pointers (None entries -> NULL); None -> NULL array."""
+    import ctypes
+    if ts is None:
+        return None
+    return (ctypes.c_void_p * len(ts))(*[ptr(t, dtype) for t in ts])
+
+
+def block_chain_supported(F_: int, H: int, W: int) -> bool:
+    return bool(lib().fdet_block_chain_supported(int(F_), int(H), int(W)))
+
+
+def block_chain_fwd(x, wpk1, b1, wpk2, b2, scales, a_out, c_out, outs, slope: float = 0.2):
+    """Run len(wpk1) un-pooled residual blocks in one launch (fdet_block_chain_fwd_bf16x3).
+    Lists of per-block tensors; `scales`, `a_out`, `c_out` may be None; `outs` entries may be None
+    except the last."""
+    nb = len(wpk1)
+    Nn, F_, H, W = x.shape
+    if not (len(b1) == len(wpk2) == len(b2) == len(outs) == nb) or outs[-1] is None:
+        raise ValueError("block_chain_fwd: inconsistent per-block lists")
+    for lst, nm in ((a_out, "a_out"), (c_out, "c_out"), (outs, "outs")):
+        for t in (lst or []):
+            if t is not None:
+                _chk4(t, (Nn, F_, H, W), nm)
+    for t in (scales or []):
+        if t is not None:
+            _chk4(t, (Nn, F_), "scale")
+    nf = packed_sizes(F_, F_)[0]
+    for t in list(wpk1) + list(wpk2):
+        if t.numel() != nf:
+            raise ValueError("block_chain_fwd: packed weight size does not match the channel count")
+    for t in list(b1) + list(b2):
+        _chk4(t, (F_,), "bias")
+    check(lib().fdet_block_chain_fwd_bf16x3(ptr(x), _ptr_array(wpk1), _ptr_array(b1), _ptr_array(wpk2), _ptr_array(b2),
+                                            _ptr_array(scales), _ptr_array(a_out), _ptr_array(c_out), _ptr_array(outs),
+                                            nb, Nn, F_, H, W, float(slope), stream()), "fdet_block_chain_fwd_bf16x3")
+
+
+def block_chain_bwd(dout, wpk1b, wpk2b, scales, a_saved, c_saved, dz1, dz2, dx, slope: float = 0.2):
+    """Data-gradient chain of the same blocks (fdet_block_chain_bwd_bf16x3): fills dz1[k], dz2[k], dx."""
+    nb = len(wpk1b)
+    Nn, F_, H, W = dout.shape
+    if not (len(wpk2b) == len(a_saved) == len(c_saved) == len(dz1) == len(dz2) == nb):
+        raise ValueError("block_chain_bwd: inconsistent per-block lists")
+    for lst, nm in ((a_saved, "a"), (c_saved, "c"), (dz1, "dz1"), (dz2, "dz2"), ([dx], "dx")):
+        for t in lst:
+            _chk4(t, (Nn, F_, H, W), nm)
+    for t in (scales or []):
+        if t is not None:
+            _chk4(t, (Nn, F_), "scale")
+    nbk = packed_sizes(F_, F_)[1]
+    for t in list(wpk1b) + list(wpk2b):
+        if t.numel() != nbk:
+            raise ValueError("block_chain_bwd: packed weight size does not match the channel count")
+    check(lib().fdet_block_chain_bwd_bf16x3(ptr(dout), _ptr_array(wpk1b), _ptr_array(wpk2b), _ptr_array(scales),
+                                            _ptr_array(a_saved), _ptr_array(c_saved), _ptr_array(dz1), _ptr_array(dz2),
+                                            ptr(dx), nb, Nn, F_, H, W, float(slope), stream()), "fdet_block_chain_bwd_bf16x3")
 
 
 def block_tail_fwd(c, x, drop_scale, out, pool: int):

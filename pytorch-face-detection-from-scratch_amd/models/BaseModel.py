@@ -69,13 +69,16 @@ class BaseModel(nn.Module):
         return self.engine.forward(x, P, masks, save=False)[0]
 
     def _preprocess(self, x: torch.Tensor) -> torch.Tensor:
-        """`self.resize(x) / 255.0` (PoolResnet.py:95) for uint8 input at the model resolution
-        (the Resize is then an identity round trip)."""
+        """`self.resize(x) / 255.0` (PoolResnet.py:91,95; BaseModel.py:64-65).  At the model
+        resolution the Resize is an identity round trip (SURVEY.md Q17) and only the /255 runs;
+        other sizes go through the on-device bilinear resize (uint8 frames stay 1 byte per pixel
+        on the way to the GPU)."""
         if x.dim() == 3:
             x = x.unsqueeze(0)
+        if not x.is_cuda:
+            raise hp.N.FdetError("preprocessing runs on the GPU only (no CPU fallback): move the frames to cuda")
         if tuple(x.shape[-2:]) != tuple(self.input_shape[1:]):
-            raise NotImplementedError("on-device bilinear Resize is not built yet: feed images at the model "
-                                      f"resolution {tuple(self.input_shape[1:])}")
+            return hp.resize_bilinear_norm(x, tuple(self.input_shape[1:]))
         if x.dtype == torch.uint8:
             return hp.u8_to_f32_norm(x)
         return x.float() / 255.0

@@ -23,7 +23,9 @@ def close(a, b, tol=1e-4):
 
 
 SHAPES = [(3, 64, 60, 60), (5, 64, 15, 15), (4, 64, 30, 30), (2, 32, 30, 30), (2, 8, 7, 9), (1, 16, 20, 20),
-          (2, 128, 15, 15), (33, 64, 15, 15)]
+          (2, 128, 15, 15), (33, 64, 15, 15),
+          # wide rows (Resnet at 480^2 / 640^2): column-segmented tiles in the bf16x3 kernels
+          (1, 64, 12, 240), (1, 32, 9, 320), (2, 64, 20, 100), (1, 16, 6, 164), (2, 64, 17, 80)]
 
 
 @pytest.mark.parametrize("x3", [False, True], ids=["f32", "bf16x3"])
@@ -34,6 +36,8 @@ def test_conv3x3_fwd_dgrad_wgrad(hp, shape, x3):
     N, C, H, W = shape
     if x3 and not hp.x3_supported(C, C):
         pytest.skip("bf16x3 needs channel counts that are multiples of 16")
+    if not x3 and W > 250:
+        pytest.skip("wide rows are built for the bf16x3 kernels only (the exact-fp32 path stops at ~250 columns)")
     g = torch.Generator().manual_seed(N * 1000 + C + H)
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(C, C, 3, 3, generator=g) * 0.1
@@ -161,3 +165,61 @@ def test_head(hp, cfg):
     close(dx, xr.grad)
     close(dW, wr.grad)
     close(db, br.grad)
+
+
+@pytest.mark.parametrize("cfg", [(3, 15, 15, 3, True), (2, 10, 10, 2, False), (5, 15, 15, 8, True), (1, 7, 9, 1, True)])
+def test_block_chain_fwd_bwd(hp, cfg):
+    """LDS-resident residual-block chain (fdet_block_chain_{fwd,bwd}_bf16x3) against torch CPU fp32:
+    forward a/c/out of every block, backward dz1/dz2 of every block and the input gradient.
+    Reference semantics: models/PoolResnet.py:33-43 with pool == 1 (conv-lrelu-conv-lrelu-dropout2d-skip)."""
+    N, H, W, nb, use_scale = cfg
+    C = 64
+    assert hp.block_chain_supported(C, H, W)
+    g = torch.Generator().manual_seed(N * 100 + H + nb)
+    x = torch.randn(N, C, H, W, generator=g)
+    Ws = [(torch.randn(C, C, 3, 3, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1,
+           torch.randn(C, C, 3, 3, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1) for _ in range(nb)]
+    scales = [((torch.rand(N, C, generator=g) > 0.25).float() / 0.75) for _ in range(nb)] if use_scale else None
+    # ---- torch reference
+    xr = x.clone().requires_grad_(True)
+    h = xr
+    a_ref, c_ref, o_ref, z1, z2 = [], [], [], [], []
+    for k in range(nb):
+        w1, b1, w2, b2 = Ws[k]
+        p1 = F.conv2d(h, w1, b1, padding=1); p1.retain_grad(); z1.append(p1)
+        a = F.leaky_relu(p1, 0.2)
+        p2 = F.conv2d(a, w2, b2, padding=1); p2.retain_grad(); z2.append(p2)
+        c = F.leaky_relu(p2, 0.2)
+        h = (c * scales[k][:, :, None, None] if use_scale else c) + h
+        a_ref.append(a); c_ref.append(c); o_ref.append(h)
+    dout = torch.randn(N, C, H, W, generator=g)
+    h.backward(dout)
+    # ---- device
+    nf, nbk = hp.packed_sizes(C, C)
+    wf1, wb1, wf2, wb2 = [], [], [], []
+    for (w1, b1, w2, b2) in Ws:
+        for w, lf, lb in ((w1, wf1, wb1), (w2, wf2, wb2)):
+            f_ = torch.empty(nf, device="cuda"); b_ = torch.empty(nbk, device="cuda")
+            hp.pack_conv3x3_weights(w.cuda(), f_, b_, x3=True)
+            lf.append(f_); lb.append(b_)
+    mk = lambda: [torch.full((N, C, H, W), float("nan"), device="cuda") for _ in range(nb)]
+    a_d, c_d, o_d = mk(), mk(), mk()
+    sc_d = [s_.cuda() for s_ in scales] if use_scale else None
+    hp.block_chain_fwd(x.cuda(), wf1, [w[1].cuda() for w in Ws], wf2, [w[3].cuda() for w in Ws], sc_d, a_d, c_d, o_d)
+    for k in range(nb):
+        close(a_d[k], a_ref[k].detach())
+        close(c_d[k], c_ref[k].detach())
+        close(o_d[k], o_ref[k].detach())
+    # eval flavour: nothing kept, only the last output
+    last = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.block_chain_fwd(x.cuda(), wf1, [w[1].cuda() for w in Ws], wf2, [w[3].cuda() for w in Ws], sc_d, None, None,
+                       [None] * (nb - 1) + [last])
+    assert torch.equal(last, o_d[-1])
+    dz1_d, dz2_d = mk(), mk()
+    dx_d = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.block_chain_bwd(dout.cuda(), wb1, wb2, sc_d, [t.detach().cuda() for t in a_ref], [t.detach().cuda() for t in c_ref],
+                       dz1_d, dz2_d, dx_d)
+    for k in range(nb):
+        close(dz1_d[k], z1[k].grad)
+        close(dz2_d[k], z2[k].grad)
+    close(dx_d, xr.grad)

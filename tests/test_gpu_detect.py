@@ -175,3 +175,35 @@ def test_cpu_tensor_is_refused(hp):
     from fdet_amd import FdetError
     with pytest.raises(FdetError):
         hp.yolo_loss_fwd_bwd(torch.rand(1, 5, 10, 10), torch.rand(1, 5, 10, 10))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 640, 640), (1, 3, 333, 500), (2, 3, 100, 160), (1, 3, 1080, 1920), (1, 3, 480, 640)])
+def test_resize_bilinear_u8_norm(hp, shape):
+    """`resize(x) / 255.0` of models/PoolResnet.py:95 for frames that are not at the model resolution.
+    Oracle: oracle.preprocess_u8 = torch CPU F.interpolate(bilinear, align_corners=False) + round + /255
+    (torchvision 0.11.2's tensor Resize; torchvision itself is absent -> parity unpinned at that boundary).
+    The interpolated value is fp32 with an ulp-level dependence on FMA contraction in the CPU build, so a
+    pixel that lands within an ulp of .5 may round the other way: at most 0.05 % of the pixels may differ,
+    and then by exactly one uint8 level."""
+    import oracle as O
+    g = torch.Generator().manual_seed(shape[2])
+    x = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+    ref = O.preprocess_u8(x, (480, 480))
+    got = hp.resize_bilinear_norm(x.cuda(), (480, 480)).cpu()
+    assert got.shape == ref.shape
+    lv = torch.round((got - ref) * 255.0).abs()
+    assert float(lv.max()) <= 1.0
+    assert float((lv > 0).float().mean()) <= 5e-4
+    same = lv == 0
+    assert torch.equal(got[same], ref[same])
+
+
+def test_resize_bilinear_f32_and_identity(hp):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 200, 300, generator=g) * 255.0
+    ref = F.interpolate(x, size=(480, 480), mode="bilinear", align_corners=False) / 255.0
+    got = hp.resize_bilinear_norm(x.cuda(), (480, 480)).cpu()
+    assert torch.allclose(got, ref, atol=1e-6, rtol=1e-6)
+    u8 = torch.randint(0, 256, (1, 3, 480, 480), dtype=torch.uint8, generator=g)
+    assert torch.equal(hp.resize_bilinear_norm(u8.cuda(), (480, 480)).cpu(), u8 / 255.0)   # Q17: identity round trip

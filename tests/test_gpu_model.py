@@ -73,7 +73,9 @@ def test_golden_train_step_autograd_path(fd, golden, name, kind, size, S, nb):
 
 
 @pytest.mark.parametrize("kind,F,size,S,nb,B", [("poolresnet", 64, 480, 10, 10, 3), ("poolresnet", 32, 480, 10, 10, 2),
-                                                ("resnet", 16, 240, 15, 6, 2)])
+                                                ("resnet", 16, 240, 15, 6, 2),
+                                                # config-3 geometry (Resnet 640^2, S=20) scaled to 320^2: 160/80/40/20 maps
+                                                ("resnet", 16, 320, 20, 5, 2)])
 def test_fused_train_steps_vs_oracle(fd, kind, F, size, S, nb, B):
     """Three fused steps (forward + loss + backward + Adam, no autograd) against the oracle's
     train_step on the same inputs and dropout masks."""
@@ -175,3 +177,27 @@ def test_basemodel_asserts_divisibility(fd):
     from fdet_amd.models.PoolResnet import PoolResnet
     with pytest.raises(AssertionError):
         PoolResnet(8, (3, 481, 481), 10)
+
+
+def test_predict_resizes_frames_on_device(fd, golden):
+    """forward(x, predict=1) with frames that are NOT at the model resolution: the bilinear Resize of
+    models/PoolResnet.py:91,95 runs on the device (fdet_resize_bilinear_u8_norm).  Oracle:
+    predict_image0 with torch CPU F.interpolate.  Trained small weights, thresholds 0.7 / 0.01."""
+    from fdet_amd.models.PoolResnet import PoolResnet
+    g = golden("g6_trained_small")
+    P = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    spec = O.poolresnet_spec(32, (3, 480, 480), 10)
+    model = PoolResnet(filters=32, input_shape=(3, 480, 480), num_of_patches=10, probability_threshold=0.7,
+                       iou_threshold=0.01)
+    model = _load(model, P).eval()
+    for n in range(g["images"].shape[0]):
+        u8 = g["images"][n]                                                    # (3,480,480) uint8
+        big = u8.repeat_interleave(4, 1).repeat_interleave(4, 2)[:, 160:160 + 1280:2, 0:1920:3].contiguous()   # (3,640,640)
+        assert tuple(big.shape) == (3, 640, 640)
+        ref = O.predict_image0(spec, P, torch.stack([big, big]), 0.7, 0.01)
+        with torch.no_grad():
+            det = model(torch.stack([big, big]).cuda(), predict=torch.tensor(1))
+        assert det.shape == ref.shape
+        if ref.shape[0]:
+            assert torch.allclose(det[:, 0].cpu(), ref[:, 0], atol=1e-4)
+            assert torch.equal(det[:, 1:].cpu(), ref[:, 1:])

@@ -1,33 +1,43 @@
 #!/usr/bin/env python3
-"""Sweep (MT,NT) tile configs of the conv3x3 kernel at the bench shapes (development aid)."""
-import os, sys, subprocess, json
+"""Sweep (MT,NT,SB) tile configs of the bf16x3 conv3x3 kernel at the bench shapes (development aid).
+One process: FDET_CONV_TILE is read by the library at every call.  Each config is also checked
+against the fp32 torch conv (max abs error printed)."""
+import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if len(sys.argv) > 1 and sys.argv[1] == "child":
-    sys.path.insert(0, ROOT)
-    import torch, fdet_amd
-    from fdet_amd import hotpath as hp
-    N, C = int(sys.argv[2]), 64
-    res = {}
-    for H in (60, 30, 15):
-        x = torch.randn(N, C, H, H, device="cuda"); w = torch.randn(C, C, 3, 3, device="cuda") * 0.05; b = torch.randn(C, device="cuda")
-        y = torch.empty_like(x); nf, nb = hp.packed_sizes(C, C)
-        wf = torch.empty(nf, device="cuda"); hp.pack_conv3x3_weights(w, wf, None)
+sys.path.insert(0, ROOT)
+import torch, fdet_amd
+from fdet_amd import hotpath as hp
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+C = 64
+cfgs = [(8, 2, 0), (8, 2, 18000), (8, 2, 36000), (4, 4, 0), (4, 4, 36000), (8, 1, 0), (8, 1, 9000)]
+
+
+def timeit(fn, reps=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True); a.record()
+    for _ in range(reps):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return a.elapsed_time(e) / reps
+
+
+for H in (60, 30, 15):
+    x = torch.randn(N, C, H, H, device="cuda"); w = torch.randn(C, C, 3, 3, device="cuda") * 0.05; b = torch.randn(C, device="cuda")
+    dz = torch.randn(N, C, H, H, device="cuda")
+    y = torch.empty_like(x); y2 = torch.empty_like(x); nf, nb = hp.packed_sizes(C, C)
+    wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda"); hp.pack_conv3x3_weights(w, wf, wb, x3=True)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x[:8], w, b, padding=1), 0.2)
+    for mt, nt, sb in cfgs:
+        os.environ["FDET_CONV_TILE"] = f"{mt},{nt}"
+        os.environ["FDET_CONV_STAGGER"] = str(sb)
         try:
-            for _ in range(2): hp.conv3x3_fwd(x, wf, b, C, y_full=y)
-            torch.cuda.synchronize()
-            a = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True); a.record()
-            for _ in range(10): hp.conv3x3_fwd(x, wf, b, C, y_full=y)
-            e.record(); torch.cuda.synchronize()
-            res[H] = a.elapsed_time(e) / 10
+            t1 = timeit(lambda: hp.conv3x3_fwd(x, wf, b, C, y_full=y, x3=True))
+            err = float((y[:8] - ref).abs().max())
+            t2 = timeit(lambda: hp.conv3x3_dgrad(dz, wb, C, y2, act=x, x3=True))
+            print(f"H={H} NW={mt} NT={nt} stagger={sb}: fwd {t1*1e3:.1f} us  dgrad+act {t2*1e3:.1f} us  maxerr {err:.2e}", flush=True)
         except Exception as ex:
-            res[H] = None
-    print(json.dumps(res))
-else:
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    cfgs = [(2, 4, st) for st in (0, 2, 5, 10, 20)] + [(2, 2, st) for st in (0, 2, 5, 10)] + [(1, 2, st) for st in (0, 1, 2, 4, 8)] + [(2, 1, st) for st in (0, 2, 4)]
-    for mt, nt, dbg in cfgs:
-        if True:
-            env = dict(os.environ, FDET_CONV_TILE=f"{mt},{nt}", FDET_CONV_STAGGER=str(dbg))
-            r = subprocess.run([sys.executable, __file__, "child", str(N)], env=env, capture_output=True, text=True)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            print(f"MT={mt} NT={nt} stagger={dbg}:", line[-1] if line else r.stderr[-300:], flush=True)
+            print(f"H={H} NW={mt} NT={nt} stagger={sb}: {str(ex)[:120]}", flush=True)
+os.environ.pop("FDET_CONV_TILE", None); os.environ.pop("FDET_CONV_STAGGER", None)
