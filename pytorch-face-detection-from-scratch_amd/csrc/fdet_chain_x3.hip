@@ -61,6 +61,28 @@ __device__ __forceinline__ void split4(const float (&f)[4], bf16x4& hi, bf16x4& 
   }
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// 4x4 dword transpose across each quad of lanes: register i of lane j <-> register j of lane i
+__device__ __forceinline__ void quad_transpose4(float (&v)[4], bool b0, bool b1) {
+#pragma unroll
+  for (int k = 0; k < 4; k += 2) {
+    const float lo = v[k], hi = v[k + 1];
+    const float recv = dpp_quad<0xB1>(b0 ? lo : hi);            // quad_perm [1,0,3,2]
+    v[k] = b0 ? recv : lo;
+    v[k + 1] = b0 ? hi : recv;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float lo = v[k], hi = v[k + 2];
+    const float recv = dpp_quad<0x4E>(b1 ? lo : hi);            // quad_perm [2,3,0,1]
+    v[k] = b1 ? recv : lo;
+    v[k + 2] = b1 ? hi : recv;
+  }
+}
+
 __global__ void __launch_bounds__(NTHR, 1)
 k_block_chain_x3(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,6 +98,11 @@ k_block_chain_x3(const ChainArgs a) {
   const bool valid = pr < a.H && pc < a.W;
   const int ebase = (n * FCH) * HW + (valid ? pr * a.W + pc : 0);   // + ch*HW
   const int xslot = q + WP + 1;                                 // slot of this position in the X arrays
+  // transposed arrangement for global I/O: this lane's 4 consecutive positions and channel offset
+  const int q4 = q & ~3, pr4 = q4 / WP, pc4 = q4 - pr4 * WP;
+  const int nv4 = pr4 < a.H ? max(0, min(4, a.W - pc4)) : 0;
+  const bool qb0 = l31 & 1, qb1 = l31 & 2;
+  const int ebase4 = (n * FCH + 4 * half + (l31 & 3)) * HW + (nv4 > 0 ? pr4 * a.W + pc4 : 0);   // + (32m + 8g)*HW
 
   {  // zero X (halo rows / pad columns stay zero for the whole chain)
     f32x4* z = reinterpret_cast<f32x4*>(smem);
@@ -85,22 +112,28 @@ k_block_chain_x3(const ChainArgs a) {
   // ---- weight staging: thread -> units of the [hi | lo] chunk image
   bf16x8 pw[NWLD];
   const int a_layer_units = 4 * A_UNITS;                        // hi (or lo) units per layer
+  // source offsets (tile invariant): unit u of the [hi | lo] chunk image <- panel unit
+  int wsrc[NWLD];
+#pragma unroll
+  for (int s_ = 0; s_ < NWLD; ++s_) {
+    const int u_ = min(tid + s_ * NTHR, 2 * A_UNITS - 1);
+    const int lo_ = u_ >= A_UNITS ? 1 : 0;
+    wsrc[s_] = lo_ * a_layer_units + (u_ - lo_ * A_UNITS);
+  }
+#define CH_ISSUE_W1(BASE, S) { pw[S] = (BASE)[wsrc[S]]; }
+#define CH_WRITE_W1(BUF, S)                                                                        \
+  {                                                                                                \
+    const int u_ = tid + (S) * NTHR;                                                               \
+    if (u_ < 2 * A_UNITS) (Wb + (BUF) * 2 * A_UNITS)[u_] = pw[S];                                  \
+  }
 #define CH_ISSUE_W(L, C16)                                                                         \
   {                                                                                                \
     const bf16x8* base_ = a.w[L] + (C16) * A_UNITS;                                                \
-    _Pragma("unroll") for (int s_ = 0; s_ < NWLD; ++s_) {                                          \
-      const int u_ = min(tid + s_ * NTHR, 2 * A_UNITS - 1);                                        \
-      const int lo_ = u_ >= A_UNITS ? 1 : 0;                                                       \
-      pw[s_] = base_[lo_ * a_layer_units + (u_ - lo_ * A_UNITS)];                                  \
-    }                                                                                              \
+    _Pragma("unroll") for (int s_ = 0; s_ < NWLD; ++s_) CH_ISSUE_W1(base_, s_)                     \
   }
 #define CH_WRITE_W(BUF)                                                                            \
   {                                                                                                \
-    bf16x8* dst_ = Wb + (BUF) * 2 * A_UNITS;                                                       \
-    _Pragma("unroll") for (int s_ = 0; s_ < NWLD; ++s_) {                                          \
-      const int u_ = tid + s_ * NTHR;                                                              \
-      if (u_ < 2 * A_UNITS) dst_[u_] = pw[s_];                                                     \
-    }                                                                                              \
+    _Pragma("unroll") for (int s_ = 0; s_ < NWLD; ++s_) CH_WRITE_W1(BUF, s_)                       \
   }
   // value of (m, r16) is channel 32m + 8*(r16>>2) + 4*half + (r16&3) at position q
 #define CH_OF(M, R) (32 * (M) + 8 * ((R) >> 2) + 4 * half + ((R) & 3))
@@ -121,20 +154,47 @@ k_block_chain_x3(const ChainArgs a) {
         }                                                                                          \
     }                                                                                              \
   }
+  // Global tile I/O, 16 bytes per lane: a 4x4 dword transpose across each quad of lanes turns
+  // (lane = position, 4 registers = 4 consecutive channels) into (lane = channel, 4 registers = 4
+  // consecutive positions of one row), so a tile moves in 8 instructions instead of 32 -- the
+  // vector-memory instruction rate of the CU, not bytes, limits a burst of dword accesses.
+  // After the transpose lane j of a quad owns channel 32m + 8g + 4*half + j at positions q4 .. q4+3.
+#define CH_LD_(BYTES)                                                                              \
+  _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                                 \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                               \
+      __builtin_memcpy(&t_[m_][g_], p_ + ebase4 + (32 * m_ + 8 * g_) * HW, BYTES);
+  // the branch on the valid count sits OUTSIDE the tile loops: eight independent loads per arm
+  // (a branch per load makes the compiler serialise every load behind an s_waitcnt)
 #define CH_LOAD_TILE(DST, PTR)                                                                     \
   {                                                                                                \
     const float* __restrict__ p_ = (PTR);                                                          \
+    f32x4 t_[2][4];                                                                                \
     _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                               \
-      _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) DST[m_][r_] = p_[ebase + CH_OF(m_, r_) * HW]; \
+      _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) t_[m_][g_] = f32x4{0.f, 0.f, 0.f, 0.f};     \
+    if (nv4 == 4) { CH_LD_(16) } else if (nv4 == 3) { CH_LD_(12) } else if (nv4 == 2) { CH_LD_(8) } else if (nv4 == 1) { CH_LD_(4) } \
+    _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                               \
+      _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                           \
+        float v_[4] = {t_[m_][g_][0], t_[m_][g_][1], t_[m_][g_][2], t_[m_][g_][3]};                \
+        quad_transpose4(v_, qb0, qb1);                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) DST[m_][4 * g_ + i_] = v_[i_];            \
+      }                                                                                            \
   }
 #define CH_STORE_TILE(PTR, V)                                                                      \
   {                                                                                                \
     float* __restrict__ p_ = (PTR);                                                                \
-    if (valid) {                                                                                   \
-      _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                             \
-        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) p_[ebase + CH_OF(m_, r_) * HW] = V[m_][r_]; \
-    }                                                                                              \
+    f32x4 t_[2][4];                                                                                \
+    _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                               \
+      _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                           \
+        float v_[4] = {V[m_][4 * g_], V[m_][4 * g_ + 1], V[m_][4 * g_ + 2], V[m_][4 * g_ + 3]};    \
+        quad_transpose4(v_, qb0, qb1);                                                             \
+        t_[m_][g_] = f32x4{v_[0], v_[1], v_[2], v_[3]};                                            \
+      }                                                                                            \
+    if (nv4 == 4) { CH_ST_(16) } else if (nv4 == 3) { CH_ST_(12) } else if (nv4 == 2) { CH_ST_(8) } else if (nv4 == 1) { CH_ST_(4) } \
   }
+#define CH_ST_(BYTES)                                                                              \
+  _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                                 \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)                                               \
+      __builtin_memcpy(p_ + ebase4 + (32 * m_ + 8 * g_) * HW, &t_[m_][g_], BYTES);
 
   // per-(image, channel) dropout scales in tile layout (1 when the pointer is null)
 #define CH_SCALE_TILE(DST, PTR)                                                                    \
@@ -188,9 +248,9 @@ k_block_chain_x3(const ChainArgs a) {
     if (a.bwd && a.ld[L]) CH_LOAD_TILE(aux, a.ld[L])
     for (int c = 0; c < 4; ++c, ++stage) {
       const bool has_next = c < 3 || L + 1 < a.nlayers;
-      if (has_next) {
-        if (c < 3) CH_ISSUE_W(L, c + 1) else CH_ISSUE_W(L + 1, 0)
-      }
+      // next weight chunk (possibly the next layer's first): one load per tap, one LDS write per
+      // later tap -- a burst at the chunk boundary would stall all eight waves on the memory pipe
+      const bf16x8* wnext = has_next ? (c < 3 ? a.w[L] + (c + 1) * A_UNITS : a.w[L + 1]) : a.w[L];
       const bf16x8* Ww = Wb + (stage & 1) * 2 * A_UNITS + w_off;
       const bf16x8* Xh = X + (c * 2 + 0) * 2 * PT + x_off;
       const bf16x8* Xl = X + (c * 2 + 1) * 2 * PT + x_off;
@@ -210,14 +270,17 @@ k_block_chain_x3(const ChainArgs a) {
           xh[nxt] = Xh[tapoff[t + 1]];
           xl[nxt] = Xl[tapoff[t + 1]];
         }
+        if (t < NWLD) CH_ISSUE_W1(wnext, t)
+        __builtin_amdgcn_sched_barrier(0);                      // keep the fragment reads one tap ahead of their MFMAs
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cur][m], xl[cur], acc[m], 0, 0, 0);
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cur][m], xh[cur], acc[m], 0, 0, 0);
           acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cur][m], xh[cur], acc[m], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t >= 9 - NWLD && has_next) CH_WRITE_W1((stage & 1) ^ 1, t - (9 - NWLD))
       }
-      if (has_next) CH_WRITE_W((stage & 1) ^ 1)
       __syncthreads();                                          // chunk consumed by every wave; next one visible
     }
 

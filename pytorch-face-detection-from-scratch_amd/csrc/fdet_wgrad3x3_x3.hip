@@ -80,6 +80,27 @@ __device__ __forceinline__ void put_split(__bf16* hi, __bf16* lo, int e, const t
   }
 }
 
+// vector load; PACK rows are only 4-byte aligned (row width not a multiple of 4)
+template <int VW, bool UNALIGNED>
+__device__ __forceinline__ typename Vec<VW>::T ldvec(const float* p) {
+  typename Vec<VW>::T v;
+  if (UNALIGNED) __builtin_memcpy(&v, p, 4 * VW);
+  else v = *reinterpret_cast<const typename Vec<VW>::T*>(p);
+  return v;
+}
+// PACK: the quad was loaded s elements to the left of its place: out[i] = i + s < 4 ? in[i + s] : 0
+template <int VW, bool PACK>
+__device__ __forceinline__ typename Vec<VW>::T pk_shift(const typename Vec<VW>::T& v, int s) {
+  if constexpr (PACK && VW == 4) {
+    f32x4 a = v;
+    if (s & 1) a = f32x4{a[1], a[2], a[3], 0.f};
+    if (s & 2) a = f32x4{a[2], a[3], 0.f, 0.f};
+    return a;
+  } else {
+    return v;
+  }
+}
+
 // one-element funnel shift across two 16-byte chunks: out = elements [s .. s+8) of (lo_chunk | hi_chunk),
 // s = 1 (SH = 0) or s = 7 (SH = 1)
 template <int SH>
@@ -105,7 +126,11 @@ __device__ __forceinline__ bf16x8 shift_chunks(const bf16x8& c_lo, const bf16x8&
 // over (dz position, x position) pairs is partitioned by dz ROW (band) and x COLUMN (segment), so a
 // segment stages its own x columns and dz columns [x0-1, x0+CW] -- lanes 14 / 15 of each 16-lane row
 // group fetch the two dz halo columns.
-template <int MTC, int VW, bool SEG>
+// PACK (VW == 4, 4 <= W <= 16): narrow rows are staged FOUR rows per 16-lane group -- lane = (row
+// sub-index, column quad) -- with 16-byte loads; the last quad of a row whose width is not a multiple
+// of 4 loads the row's last four elements and shifts them into place (branch-free, never reads past
+// the row).  One dword-per-lane staging pass per row made the 15x15 layers instruction-issue bound.
+template <int MTC, int VW, bool SEG, bool PACK = false>
 __global__ void __launch_bounds__(NTHR, 1)
 k_wgrad3x3_x3(const WgX3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -153,6 +178,10 @@ k_wgrad3x3_x3(const WgX3Args a) {
   const int chl = tid >> 4;
   int x0 = 0, wcur = W;                               // current segment
   bool lane_ok = xv < W / VW;
+  // PACK geometry: column quad / row sub-index of this lane, load offset and right shift of the quad
+  const int xq = tid & 3, rsub = (tid >> 2) & 3;
+  const int pk_c0 = min(4 * xq, W - 4), pk_s = 4 * xq - pk_c0;
+  if (PACK) lane_ok = 4 * xq < W;
   const int co0 = cob * MB, ci0 = cib * 32;
   const int HW = a.H * W;
   float bpart[ZCH];
@@ -174,26 +203,28 @@ k_wgrad3x3_x3(const WgX3Args a) {
     const int hcol_ = xv == 14 ? x0 - 1 : x0 + wcur;                                              \
     const bool hok_ = SEG && xv >= 14 && hcol_ >= 0 && hcol_ < W;                                 \
     _Pragma("unroll") for (int r_ = 0; r_ < RZ; ++r_) {                                           \
-      const int v = (V0) + r_;                                                                    \
+      const int rr_ = PACK ? 4 * r_ + rsub : r_;                                                  \
+      const int v = (V0) + rr_;                                                                   \
       const int n = fdiv(v, a.magic_h1), yy = v - n * H1 - 1;                                     \
-      const bool rok = r_ < R && v < a.VR && yy >= 0;                                             \
+      const bool rok = rr_ < R && v < a.VR && yy >= 0;                                            \
       const float* rowp = gdz + ((size_t)n * a.Cout * a.H + yy) * W;                             \
       _Pragma("unroll") for (int c_ = 0; c_ < ZCH; ++c_) {                                        \
         const int ch = co0 + c_ * 16 + chl;                                                       \
         pz[c_][r_] = (rok && lane_ok && ch < a.Cout)                                              \
-                         ? *reinterpret_cast<const VT*>(rowp + (size_t)ch * HW + x0 + xv * VW) : vzero<VW>(); \
+                         ? pk_shift<VW, PACK>(ldvec<VW, PACK>(rowp + (size_t)ch * HW + x0 + (PACK ? pk_c0 : xv * VW)), pk_s) : vzero<VW>(); \
         if (SEG) pzh[c_][r_] = (rok && hok_ && ch < a.Cout) ? rowp[(size_t)ch * HW + hcol_] : 0.f; \
       }                                                                                           \
     }                                                                                             \
     _Pragma("unroll") for (int r_ = 0; r_ < RX; ++r_) {                                           \
-      const int v = (V0) - 1 + r_;                                                                \
+      const int rr_ = PACK ? 4 * r_ + rsub : r_;                                                  \
+      const int v = (V0) - 1 + rr_;                                                               \
       const int n = fdiv(max(v, 0), a.magic_h1), yy = v - n * H1 - 1;                             \
-      const bool rok = r_ < R + 2 && v >= 0 && v < a.VR && yy >= 0;                               \
+      const bool rok = rr_ < R + 2 && v >= 0 && v < a.VR && yy >= 0;                              \
       const float* rowp = gx + ((size_t)n * a.Cin * a.H + yy) * W;                               \
       _Pragma("unroll") for (int c_ = 0; c_ < XCH; ++c_) {                                        \
         const int ch = ci0 + c_ * 16 + chl;                                                       \
         px[c_][r_] = (rok && lane_ok && ch < a.Cin)                                               \
-                         ? *reinterpret_cast<const VT*>(rowp + (size_t)ch * HW + x0 + xv * VW) : vzero<VW>(); \
+                         ? pk_shift<VW, PACK>(ldvec<VW, PACK>(rowp + (size_t)ch * HW + x0 + (PACK ? pk_c0 : xv * VW)), pk_s) : vzero<VW>(); \
       }                                                                                           \
     }                                                                                             \
   }
@@ -201,19 +232,21 @@ k_wgrad3x3_x3(const WgX3Args a) {
   {                                                                                               \
     if (SEG ? xv < 14 : lane_ok) {                                                                \
       _Pragma("unroll") for (int r_ = 0; r_ < RZ; ++r_) {                                         \
-        if (r_ < R) {                                                                             \
+        const int rr_ = PACK ? 4 * r_ + rsub : r_;                                                \
+        if (rr_ < R) {                                                                            \
           _Pragma("unroll") for (int c_ = 0; c_ < ZCH; ++c_) {                                    \
             const int row_ = (c_ * 16 + chl) * a.QZ;                                              \
-            put_split<VW>(Zh + row_, Zl + row_, ZP + r_ * P + xv * VW, pz[c_][r_]);               \
+            put_split<VW>(Zh + row_, Zl + row_, ZP + rr_ * P + (PACK ? 4 * xq : xv * VW), pz[c_][r_]); \
             _Pragma("unroll") for (int k_ = 0; k_ < VW; ++k_) bpart[c_] += vget<VW>(pz[c_][r_], k_); \
           }                                                                                       \
         }                                                                                         \
       }                                                                                           \
       _Pragma("unroll") for (int r_ = 0; r_ < RX; ++r_) {                                         \
-        if (r_ < R + 2) {                                                                         \
+        const int rr_ = PACK ? 4 * r_ + rsub : r_;                                                \
+        if (rr_ < R + 2) {                                                                        \
           _Pragma("unroll") for (int c_ = 0; c_ < XCH; ++c_) {                                    \
             const int row_ = (c_ * 16 + chl) * a.PX;                                              \
-            put_split<VW>(Xh + row_, Xl + row_, XP + r_ * P + xv * VW, px[c_][r_]);               \
+            put_split<VW>(Xh + row_, Xl + row_, XP + rr_ * P + (PACK ? 4 * xq : xv * VW), px[c_][r_]); \
           }                                                                                       \
         }                                                                                         \
       }                                                                                           \
@@ -353,11 +386,15 @@ k_wgx3_reduce(const float* __restrict__ ws_all, const float* __restrict__ wsb_al
 
 unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
-struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw, NSEG, CW; size_t lds, ws_floats; bool ok; };
+struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw, NSEG, CW, pack; size_t lds, ws_floats; bool ok; };
 
 WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   WgX3Plan p{};
   p.vw = (W % 4 == 0) ? 4 : (W % 2 == 0 ? 2 : 1);
+  // four narrow rows per 16-lane group: opt-in (FDET_WGRAD_PACK=1) -- measured SLOWER than the
+  // dword-per-lane staging on the 15x15 layers (0.64 vs 0.50 ms per 16 layers), kept for tuning
+  p.pack = (W >= 4 && W <= 16 && getenv("FDET_WGRAD_PACK") != nullptr) ? 1 : 0;
+  if (p.pack) p.vw = 4;
   p.NSEG = 1; p.CW = W;
   if (W / p.vw > 16 && p.vw == 4) { p.CW = 56; p.NSEG = (W + 55) / 56; }     // column segments (14 vector lanes)
   p.P = p.NSEG > 1 ? 64 : (W + 1 + 7) / 8 * 8;
@@ -365,11 +402,12 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   p.CoP = (Cout + 31) / 32 * 32;
   p.CiP = (Cin + 31) / 32 * 32;
   p.MTC = (p.CoP % 64 == 0) ? 2 : 1;
-  const int wv = p.CW / p.vw;
+  const int wv = p.pack ? 4 : p.CW / p.vw;
   p.ok = wv <= 16 && p.VR < (1 << 20) && (size_t)N * std::max(Cin, Cout) * H * W < ((size_t)1 << 31);
   const int rows_total = p.VR - 1;
   const int zch = p.MTC * 2;
-  const int rz = zreg(p.vw) / (zch * p.vw), rx = xreg(p.vw) / (2 * p.vw);
+  const int rmul = p.pack ? 4 : 1;
+  const int rz = rmul * (zreg(p.vw) / (zch * p.vw)), rx = rmul * (xreg(p.vw) / (2 * p.vw));
   int bestR = 0; double bestC = 1e30;
   for (int r = 1; r <= rz && r + 2 <= rx && r <= rows_total; ++r) {
     const int Q = r * p.P;
@@ -407,6 +445,7 @@ void launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) 
     hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds, st, a);
   };
   if (p.NSEG > 1) go(k_wgrad3x3_x3<MTC, 4, true>);
+  else if (p.pack) go(k_wgrad3x3_x3<MTC, 4, false, true>);
   else if (p.vw == 4) go(k_wgrad3x3_x3<MTC, 4, false>);
   else if (p.vw == 2) go(k_wgrad3x3_x3<MTC, 2, false>);
   else go(k_wgrad3x3_x3<MTC, 1, false>);
