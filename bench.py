@@ -170,15 +170,16 @@ def main():
         value = world * B * args.steps / dt
         # ---- roofline of the dominant kernel (live HIP-event timing over the timed region, on the
         # stream the kernels are launched on).  The 3x3 conv forward / data-gradient share ONE kernel
-        # (k_conv3x3_x3 in bf16x3 arithmetic, k_conv3x3 in fp32); its launches at one resolution are
-        # pooled.  bf16x3 convs are HBM-bound (peak 8 TB/s); the exact-fp32 path is bound by the
-        # fp32 MFMA rate (157.3 TFLOP/s).
+        # symbol (k_conv3x3_x3_sb<2,2> in bf16x3 arithmetic at 60x60 and 30x30, k_conv3x3 in fp32):
+        # every launch of that symbol is pooled, so avg_launch_ms is the average rocprofv3 --stats
+        # reports for it.  bf16x3 convs are HBM-bound (peak 8 TB/s); the exact-fp32 path is bound by
+        # the fp32 MFMA rate (157.3 TFLOP/s).
         per = timer.summary()                                # name -> (launches, total ms, flops/launch, bytes/launch)
         x3 = bool(model.engine.x3)
         groups = {}
         for k, (n_l, tot, fl, nb) in per.items():
             kind, shape = k.split("@")
-            g = ("conv3x3_fwd+dgrad@" + shape) if kind in ("conv3x3_fwd", "conv3x3_dgrad") else k
+            g = "conv3x3_fwd+dgrad" if kind in ("conv3x3_fwd", "conv3x3_dgrad") else k
             a = groups.setdefault(g, [0, 0.0, 0.0, 0.0])
             a[0] += n_l; a[1] += tot; a[2] += fl * n_l; a[3] += nb * n_l
         dom = max(groups, key=lambda k: groups[k][1])
