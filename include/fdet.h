@@ -169,6 +169,9 @@ int fdet_conv3x3_dgrad(const float* dz, const float* wpk, const float* act, cons
  * panels (same buffers can be reused); they are not interchangeable with them. */
 int fdet_pack_conv3x3_weights_bf16x3(const float* w, int Cout, int Cin, void* wpk_fwd, void* wpk_bwd,
                                      void* stream);
+/* L same-shape layers in one launch; h_* are HOST arrays of L device pointers (either panel array may be NULL). */
+int fdet_pack_conv3x3_weights_bf16x3_batched(const float* const* h_w, int L, int Cout, int Cin,
+                                             void* const* h_wpk_fwd, void* const* h_wpk_bwd, void* stream);
 int fdet_conv3x3_fwd_bf16x3(const float* x, const void* wpk, const float* bias, float* y_full,
                             const float* skip, const float* drop_scale, float* y_out,
                             int N, int Cin, int Cout, int H, int W, int pool, float slope, void* stream);

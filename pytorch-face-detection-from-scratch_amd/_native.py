@@ -57,6 +57,7 @@ SIGNATURES = {
     "fdet_conv3x3_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_dgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_pack_conv3x3_weights_bf16x3": (_I, [_P, _I, _I, _P, _P, _P]),
+    "fdet_pack_conv3x3_weights_bf16x3_batched": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "fdet_conv3x3_fwd_bf16x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_dgrad_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_wgrad_ws_bytes": (_SZ, [_I, _I, _I, _I, _I]),

@@ -150,13 +150,17 @@ class ConvStack:
         F_ = self.geo.filters
         nf, nb = hp.packed_sizes(F_, F_)
         dev = P["conv1.weight"].device
-        for k in range(self.geo.num_blocks):
-            for j in (1, 2):
-                name = f"residual_blocks.{k}.conv{j}"
-                if name + ".f" not in self._wpk:
-                    self._wpk[name + ".f"] = torch.empty(nf, dtype=F32, device=dev)
-                    self._wpk[name + ".b"] = torch.empty(nb, dtype=F32, device=dev)
-                hp.pack_conv3x3_weights(P[name + ".weight"], self._wpk[name + ".f"], self._wpk[name + ".b"], x3=self.x3)
+        names = [f"residual_blocks.{k}.conv{j}" for k in range(self.geo.num_blocks) for j in (1, 2)]
+        for name in names:
+            if name + ".f" not in self._wpk:
+                self._wpk[name + ".f"] = torch.empty(nf, dtype=F32, device=dev)
+                self._wpk[name + ".b"] = torch.empty(nb, dtype=F32, device=dev)
+        if self.x3:                                        # every layer in one launch
+            hp.pack_conv3x3_weights_batched([P[nm + ".weight"] for nm in names], [self._wpk[nm + ".f"] for nm in names],
+                                            [self._wpk[nm + ".b"] for nm in names])
+        else:
+            for name in names:
+                hp.pack_conv3x3_weights(P[name + ".weight"], self._wpk[name + ".f"], self._wpk[name + ".b"], x3=False)
         self._packed_key = key
 
     def mark_params_dirty(self):

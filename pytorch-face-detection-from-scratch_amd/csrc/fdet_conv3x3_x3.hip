@@ -11,7 +11,9 @@
 
 namespace {
 
-long long* g_probe_stamps = nullptr;   // set only by the diagnostic build's fdet_x3_probe_set
+long long* g_probe_stamps = nullptr;
+constexpr int PACK_MAXL = 32;
+struct PackBatch { const float* w[PACK_MAXL]; bf16x8* fwd[PACK_MAXL]; bf16x8* bwd[PACK_MAXL]; };   // set only by the diagnostic build's fdet_x3_probe_set
 
 // ---------------------------------------------------------------------------------------
 // weight panels: split fp32 OIHW weights into bf16 hi/lo, K-major per 16-channel chunk
@@ -189,6 +191,58 @@ extern "C" int fdet_pack_conv3x3_weights_bf16x3(const float* w, int Cout, int Ci
   hipLaunchKernelGGL(k_pack3x3_x3, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, CoP, CiP,
                      (bf16x8*)wpk_fwd, (bf16x8*)wpk_bwd);
   return check_launch("fdet_pack_conv3x3_weights_bf16x3");
+}
+
+__global__ void __launch_bounds__(256)
+k_pack3x3_x3_batched(const PackBatch b, int Cout, int Cin, int CoP, int CiP) {
+  const float* __restrict__ w = b.w[blockIdx.y];
+  bf16x8* __restrict__ fwd = b.fwd[blockIdx.y];
+  bf16x8* __restrict__ bwd = b.bwd[blockIdx.y];
+  const int nf = (Cin / 16) * 9 * 2 * CoP, nb = (Cout / 16) * 9 * 2 * CiP;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (fwd && t < nf) {
+    const int co = t % CoP, r = t / CoP;
+    const int h = r & 1, r2 = r >> 1, tap = r2 % 9, c16 = r2 / 9;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (co < Cout) ? w[((size_t)co * Cin + c16 * 16 + 8 * h + j) * 9 + tap] : 0.f;
+    bf16x8 hi, lo;
+    split8(f, hi, lo);
+    fwd[t] = hi;
+    fwd[nf + t] = lo;
+  }
+  if (bwd && t < nb) {
+    const int ci = t % CiP, r = t / CiP;
+    const int h = r & 1, r2 = r >> 1, tap = r2 % 9, o16 = r2 / 9;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (ci < Cin) ? w[((size_t)(o16 * 16 + 8 * h + j) * Cin + ci) * 9 + (8 - tap)] : 0.f;
+    bf16x8 hi, lo;
+    split8(f, hi, lo);
+    bwd[t] = hi;
+    bwd[nb + t] = lo;
+  }
+}
+
+extern "C" int fdet_pack_conv3x3_weights_bf16x3_batched(const float* const* h_w, int L, int Cout, int Cin,
+                                                        void* const* h_wpk_fwd, void* const* h_wpk_bwd, void* stream) {
+  FDET_REQUIRE(h_w && L >= 1 && Cout > 0 && Cin > 0 && (h_wpk_fwd || h_wpk_bwd), "pack_conv3x3_weights_bf16x3_batched: bad arguments");
+  FDET_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "pack_conv3x3_weights_bf16x3_batched: channel counts must be multiples of 16 (Cin=%d Cout=%d)", Cin, Cout);
+  const int CoP = (Cout + 31) / 32 * 32, CiP = (Cin + 31) / 32 * 32;
+  const int n = max((Cin / 16) * 9 * 2 * CoP, (Cout / 16) * 9 * 2 * CiP);
+  for (int l0 = 0; l0 < L; l0 += PACK_MAXL) {
+    const int nl = min(PACK_MAXL, L - l0);
+    PackBatch b{};
+    for (int l = 0; l < nl; ++l) {
+      FDET_REQUIRE(h_w[l0 + l], "pack_conv3x3_weights_bf16x3_batched: null weight pointer (layer %d)", l0 + l);
+      b.w[l] = h_w[l0 + l];
+      b.fwd[l] = h_wpk_fwd ? (bf16x8*)h_wpk_fwd[l0 + l] : nullptr;
+      b.bwd[l] = h_wpk_bwd ? (bf16x8*)h_wpk_bwd[l0 + l] : nullptr;
+    }
+    hipLaunchKernelGGL(k_pack3x3_x3_batched, dim3((n + 255) / 256, nl), dim3(256), 0, (hipStream_t)stream, b, Cout, Cin, CoP, CiP);
+    if (int rc = check_launch("fdet_pack_conv3x3_weights_bf16x3_batched")) return rc;
+  }
+  return FDET_OK;
 }
 
 extern "C" int fdet_conv3x3_fwd_bf16x3(const float* x, const void* wpk, const float* bias, float* y_full,

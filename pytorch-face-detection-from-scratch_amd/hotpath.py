@@ -125,16 +125,20 @@ def step_metrics(gt: torch.Tensor, gt_counts: torch.Tensor, pred: torch.Tensor, 
     return per, tot
 
 
-def u8_to_f32_norm(x: torch.Tensor) -> torch.Tensor:
+def u8_to_f32_norm(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     if x.dtype != torch.uint8:
         raise TypeError("u8_to_f32_norm expects uint8")
     x = x.contiguous()
-    out = torch.empty(x.shape, dtype=F32, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape, dtype=F32, device=x.device)
+    elif tuple(out.shape) != tuple(x.shape):
+        raise ValueError("u8_to_f32_norm: out shape differs")
     check(lib().fdet_u8_to_f32_norm(ptr(x, torch.uint8), ptr(out), x.numel(), stream()), "fdet_u8_to_f32_norm")
     return out
 
 
-def resize_bilinear_norm(x: torch.Tensor, size: Tuple[int, int], divisor: float = 255.0) -> torch.Tensor:
+def resize_bilinear_norm(x: torch.Tensor, size: Tuple[int, int], divisor: float = 255.0,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`Resize(size)(x) / 255.0` on the device (torchvision 0.11.2 tensor semantics: bilinear,
     align_corners=False, no antialias).  uint8 input goes through the uint8 round trip (round half
     even) before the division; float input is interpolated and divided.  (N,C,H,W) or (C,H,W)."""
@@ -145,7 +149,10 @@ def resize_bilinear_norm(x: torch.Tensor, size: Tuple[int, int], divisor: float 
     x = x.contiguous()
     Nn, C, Hs, Ws = x.shape
     Hd, Wd = int(size[0]), int(size[1])
-    out = torch.empty(Nn, C, Hd, Wd, dtype=F32, device=x.device)
+    if out is None:
+        out = torch.empty(Nn, C, Hd, Wd, dtype=F32, device=x.device)
+    else:
+        _chk4(out, (Nn, C, Hd, Wd), "out")
     if x.dtype == torch.uint8:
         if divisor != 255.0:
             raise ValueError("resize_bilinear_norm: the uint8 path always divides by 255")
@@ -207,6 +214,23 @@ def pack_conv3x3_weights(w: torch.Tensor, wpk_fwd: Optional[torch.Tensor], wpk_b
         raise ValueError(f"wpk_bwd must hold {nb} floats")
     fn = lib().fdet_pack_conv3x3_weights_bf16x3 if x3 else lib().fdet_pack_conv3x3_weights
     check(fn(ptr(w), cout, cin, ptr(wpk_fwd), ptr(wpk_bwd), stream()), "fdet_pack_conv3x3_weights")
+
+
+def pack_conv3x3_weights_batched(ws, wpk_fwds, wpk_bwds) -> None:
+    """bf16x3 panels of len(ws) same-shape layers in one launch."""
+    cout, cin, kh, kw = ws[0].shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("pack_conv3x3_weights_batched: 3x3 kernels only")
+    nf, nb = packed_sizes(cout, cin)
+    for w, f_, b_ in zip(ws, wpk_fwds, wpk_bwds):
+        _chk4(w, (cout, cin, 3, 3), "w")
+        if f_.numel() != nf or b_.numel() != nb:
+            raise ValueError("pack_conv3x3_weights_batched: packed buffer size does not match (Cout,Cin)")
+    import ctypes
+    arr = ctypes.c_void_p * len(ws)
+    check(lib().fdet_pack_conv3x3_weights_bf16x3_batched(arr(*[ptr(w) for w in ws]), len(ws), cout, cin,
+                                                         arr(*[ptr(t) for t in wpk_fwds]), arr(*[ptr(t) for t in wpk_bwds]),
+                                                         stream()), "fdet_pack_conv3x3_weights_bf16x3_batched")
 
 
 def conv3x3_fwd(x, wpk, bias, cout: int, y_full=None, skip=None, drop_scale=None, y_out=None, slope: float = 0.2,

@@ -201,3 +201,24 @@ def test_predict_resizes_frames_on_device(fd, golden):
         if ref.shape[0]:
             assert torch.allclose(det[:, 0].cpu(), ref[:, 0], atol=1e-4)
             assert torch.equal(det[:, 1:].cpu(), ref[:, 1:])
+
+
+def test_u8_feeder_matches_direct_path(fd):
+    """Pinned double-buffered uint8 feed (datasets/feed.py) delivers exactly what the direct
+    `x.cuda()` + /255 path delivers, at the model resolution and through the on-device resize."""
+    from fdet_amd.datasets.feed import U8BatchFeeder
+    from fdet_amd import hotpath as hp
+    g = torch.Generator().manual_seed(9)
+    for shape in ((4, 3, 480, 480), (2, 3, 300, 400)):
+        feeder = U8BatchFeeder(shape, (480, 480), "cuda", target_shape=(shape[0], 5, 10, 10), depth=2)
+        batches = [(torch.randint(0, 256, shape, dtype=torch.uint8, generator=g), torch.rand(shape[0], 5, 10, 10, generator=g))
+                   for _ in range(5)]
+        feeder.submit(*batches[0])
+        for i in range(len(batches)):
+            if i + 1 < len(batches):
+                feeder.submit(*batches[i + 1])
+            x, y, tok = feeder.get()
+            ref = hp.resize_bilinear_norm(batches[i][0].cuda(), (480, 480))
+            assert torch.equal(x, ref)
+            assert torch.equal(y.cpu(), batches[i][1])
+            feeder.release(tok)
