@@ -5,6 +5,7 @@
 // (fdet_conv3x3_x3_kernel.inc).  Same arithmetic, LDS layout and epilogue fusion modes as described there.
 #include "fdet_conv_common.h"
 #include <algorithm>
+#include <cstdint>
 
 using namespace fdet;
 
@@ -12,8 +13,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int CK16 = 16;     // input channels per chunk (= MFMA K)
-// B staging slots per thread (8 fp32 loads each): 2*(R+2)*W <= nbs*NTHR is checked on the host
-__host__ __device__ constexpr int nbs_of(int nt) { return nt == 4 ? 5 : 3; }
+// B staging slots per thread (8 loads of VW floats each): 2*(R+2)*(W/VW) <= nbs*NTHR is checked on the host
+__host__ __device__ constexpr int nbs_of(int nt, int vw) { return vw == 4 ? 1 : (vw == 2 ? 2 : 3); }
 
 struct X3SbArgs {
   ConvArgs c;                // x, bias, epilogue pointers, geometry (WP, R, VR, nbands, mode ...)
@@ -35,10 +36,136 @@ __device__ __forceinline__ void split8(const float (&f)[8], bf16x8& hi, bf16x8& 
 
 // Single LDS buffer (<= 80 KB, <= 256 registers): two workgroups share a CU, and one's staging /
 // epilogue runs beside the other's MFMAs.
-template <int MT, int NT>
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// 4x4 dword transpose across each quad of lanes: register i of lane j <-> register j of lane i
+__device__ __forceinline__ void quad_transpose4(float (&v)[4], bool b0, bool b1) {
+#pragma unroll
+  for (int k = 0; k < 4; k += 2) {
+    const float lo = v[k], hi = v[k + 1];
+    const float recv = dpp_quad<0xB1>(b0 ? lo : hi);            // quad_perm [1,0,3,2]
+    v[k] = b0 ? recv : lo;
+    v[k + 1] = b0 ? hi : recv;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float lo = v[k], hi = v[k + 2];
+    const float recv = dpp_quad<0x4E>(b1 ? lo : hi);            // quad_perm [2,3,0,1]
+    v[k] = b1 ? recv : lo;
+    v[k + 2] = b1 ? hi : recv;
+  }
+}
+
+// Epilogue with 16-byte global accesses.  The MFMA leaves lane = position, 4 registers = 4
+// consecutive channels; a 4x4 dword transpose across each quad of lanes gives lane = channel,
+// 4 registers = 4 consecutive positions of one row (WP % 4 == 0, so a quad never straddles rows):
+// 16 memory instructions per tensor instead of 64, each covering 128-byte runs.  Loads of all
+// tiles first, then arithmetic, then stores; the branch on the valid count sits outside the loops.
+template <int MT, int NT, int MODE>
+__device__ __forceinline__ void epilogue_sb(const ConvArgs& a, f32x16 (&acc)[MT][NT], int v0, int qwave, int cob0,
+                                            int l31, int half) {
+  const float* __restrict__ g_bias = a.bias;
+  const float* __restrict__ g_skip = a.skip;
+  const float* __restrict__ g_scale = a.scale;
+  const float* __restrict__ g_act = a.act;
+  float* __restrict__ g_full = a.y_full;
+  float* __restrict__ g_out = a.y_out;
+  const int H1 = a.H + 1, HW = a.H * a.W;
+  const bool b0 = l31 & 1, b1 = l31 & 2;
+  const int j = l31 & 3;
+  constexpr bool FWD = MODE == EPI_FWD_FULL || MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT;
+  constexpr bool HAS_LD = MODE != EPI_FWD_FULL;
+  const float* __restrict__ src = MODE == EPI_DGRAD_ACT ? g_act : g_skip;
+  int nv[NT], idx0[NT], img[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int q4 = qwave + n * 32 + (l31 & ~3);
+    const int tr = q4 / a.WP, ox = q4 - tr * a.WP;
+    const int v = v0 + tr;
+    const int im = fdiv(v, a.magic_h1), oy = v - im * H1 - 1;
+    const bool ok = tr < a.R && v < a.VR && oy >= 0 && ox < a.W;
+    nv[n] = ok ? min(4, a.W - ox) : 0;
+    img[n] = ok ? im : 0;
+    idx0[n] = (ok ? ((im * a.Cout) * a.H + oy) * a.W + ox : 0) + (cob0 + 4 * half + j) * HW;   // + (32m + 8g)*HW
+  }
+  // transposed accumulators: t[m][n][g][i] = channel cob0 + 32m + 8g + 4half + j, position q4 + i
+  f32x4 t[MT][NT][4], u[HAS_LD ? MT : 1][HAS_LD ? NT : 1][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v_[4] = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+        quad_transpose4(v_, b0, b1);
+        t[m][n][g] = f32x4{v_[0], v_[1], v_[2], v_[3]};
+      }
+  float bz[MT][4], sc[MT][NT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch = cob0 + 32 * m + 8 * g + 4 * half + j;
+      bz[m][g] = FWD ? g_bias[ch] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) sc[m][n][g] = MODE == EPI_FWD_BOTH ? g_scale[img[n] * a.Cout + ch] : 1.f;
+    }
+#define SB_LD(BYTES)                                                                               \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int g = 0; g < 4; ++g)     \
+    __builtin_memcpy(&u[m][n][g], src + idx0[n] + (32 * m + 8 * g) * HW, BYTES);
+  if (HAS_LD) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) u[m][n][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (nv[n] == 4) { SB_LD(16) } else if (nv[n] == 3) { SB_LD(12) } else if (nv[n] == 2) { SB_LD(8) } else if (nv[n] == 1) { SB_LD(4) }
+    }
+  }
+#undef SB_LD
+  // arithmetic for every lane (t <- value for y_full / dx, u <- value for y_out)
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float z = t[m][n][g][i];
+          if (FWD) {
+            const float w_ = z + bz[m][g];
+            z = w_ > 0.f ? w_ : w_ * a.slope;
+            if (MODE == EPI_FWD_BOTH) u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i] = z * sc[m][n][g] + u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i];
+            if (MODE == EPI_FWD_OUT) u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i] = z + u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i];
+          } else if (MODE == EPI_DGRAD_ACT) {
+            z *= (u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i] > 0.f) ? 1.f : a.slope;
+          } else {
+            z += u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i];
+          }
+          t[m][n][g][i] = z;
+        }
+#define SB_ST(BYTES)                                                                               \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int g = 0; g < 4; ++g) {   \
+    const int idx_ = idx0[n] + (32 * m + 8 * g) * HW;                                              \
+    if (MODE != EPI_FWD_OUT) __builtin_memcpy(g_full + idx_, &t[m][n][g], BYTES);                  \
+    if (MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT) __builtin_memcpy(g_out + idx_, &u[HAS_LD ? m : 0][HAS_LD ? n : 0][g], BYTES); \
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    if (nv[n] == 4) { SB_ST(16) } else if (nv[n] == 3) { SB_ST(12) } else if (nv[n] == 2) { SB_ST(8) } else if (nv[n] == 1) { SB_ST(4) }
+  }
+#undef SB_ST
+}
+
+template <int MT, int NT, int VW>
 __global__ void __launch_bounds__(NTHR, 2)
 k_conv3x3_x3_sb(const X3SbArgs p) {
-  constexpr int NBS = nbs_of(NT);
+  constexpr int NBS = nbs_of(NT, VW);
+  using VT = typename Vec<VW>::T;
   const ConvArgs& a = p.c;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MB = MT * 32;
@@ -68,7 +195,7 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     if (it < 2 * p.p_in) {
       const int h = it >= p.p_in ? 1 : 0;
       const int pp = it - h * p.p_in;
-      const int tr = fdiv(pp, p.magic_w), ix = pp - tr * a.W;
+      const int tr = fdiv(pp, p.magic_w), ix = (pp - tr * (a.W / VW)) * VW;
       const int v = v0 - 1 + tr;
       if (v >= 0 && v < a.VR) {
         const int n = fdiv(v, a.magic_h1), yy = v - n * H1 - 1;
@@ -81,7 +208,7 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
   }
   const int a_chunk_units = 9 * 2 * a.CoP;            // units per chunk per array in HBM
   bf16x8 pa[NA];
-  float pb[NBS][8];
+  VT pb[NBS][8];
 #define X3_ISSUE_LOADS(C16)                                                                        \
   {                                                                                                \
     _Pragma("unroll") for (int s_ = 0; s_ < NA; ++s_) {                                            \
@@ -95,7 +222,7 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     const float* xs_ = a.x + (size_t)(C16) * CK16 * HW;                                            \
     _Pragma("unroll") for (int s_ = 0; s_ < NBS; ++s_) {                                           \
       const float* q_ = xs_ + max(b_src[s_], 0);                                                   \
-      _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) pb[s_][j_] = q_[j_ * HW];                   \
+      _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) pb[s_][j_] = *reinterpret_cast<const VT*>(q_ + j_ * HW); \
     }                                                                                              \
   }
 #define X3_WRITE_LDS(BUF)                                                                          \
@@ -108,10 +235,14 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     bf16x8* B_ = buf_ + 2 * A_UNITS;                                                               \
     _Pragma("unroll") for (int s_ = 0; s_ < NBS; ++s_) {                                           \
       if (b_src[s_] >= 0) {                                                                        \
-        bf16x8 hi_, lo_;                                                                           \
-        split8(pb[s_], hi_, lo_);                                                                  \
-        B_[b_dst[s_]] = hi_;                                                                       \
-        B_[b_dst[s_] + 2 * PT] = lo_;                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < VW; ++i_) {                                        \
+          float f_[8];                                                                             \
+          _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) f_[j_] = vget<VW>(pb[s_][j_], i_);      \
+          bf16x8 hi_, lo_;                                                                         \
+          split8(f_, hi_, lo_);                                                                    \
+          B_[b_dst[s_] + i_] = hi_;                                                                \
+          B_[b_dst[s_] + i_ + 2 * PT] = lo_;                                                       \
+        }                                                                                          \
       }                                                                                            \
     }                                                                                              \
   }
@@ -174,7 +305,17 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     }
   }
 
-  // ---- epilogue (shared with the fp32 kernel: same accumulator layout)
+  // ---- epilogue: fast modes through the quad transpose (16-byte accesses), GENERIC through the
+  //      channel-per-register epilogue shared with the fp32 kernel
+  const int cob0_t = mb * MB;
+  switch (a.mode) {
+    case EPI_FWD_FULL: epilogue_sb<MT, NT, EPI_FWD_FULL>(a, acc, v0, qwave, cob0_t, l31, half); return;
+    case EPI_FWD_BOTH: epilogue_sb<MT, NT, EPI_FWD_BOTH>(a, acc, v0, qwave, cob0_t, l31, half); return;
+    case EPI_FWD_OUT: epilogue_sb<MT, NT, EPI_FWD_OUT>(a, acc, v0, qwave, cob0_t, l31, half); return;
+    case EPI_DGRAD_ACT: epilogue_sb<MT, NT, EPI_DGRAD_ACT>(a, acc, v0, qwave, cob0_t, l31, half); return;
+    case EPI_DGRAD_ADD: epilogue_sb<MT, NT, EPI_DGRAD_ADD>(a, acc, v0, qwave, cob0_t, l31, half); return;
+    default: break;
+  }
   const int qlimit = a.R * WP;
   bool okn[NT];
   size_t basen[NT];
@@ -190,20 +331,18 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     imgn[n] = img;
   }
   const int cob0 = mb * MB + 4 * half;
-  switch (a.mode) {
-    case EPI_FWD_FULL: epilogue<MT, NT, EPI_FWD_FULL>(a, acc, okn, basen, imgn, cob0, HW); break;
-    case EPI_FWD_BOTH: epilogue<MT, NT, EPI_FWD_BOTH>(a, acc, okn, basen, imgn, cob0, HW); break;
-    case EPI_FWD_OUT: epilogue<MT, NT, EPI_FWD_OUT>(a, acc, okn, basen, imgn, cob0, HW); break;
-    case EPI_DGRAD_ACT: epilogue<MT, NT, EPI_DGRAD_ACT>(a, acc, okn, basen, imgn, cob0, HW); break;
-    case EPI_DGRAD_ADD: epilogue<MT, NT, EPI_DGRAD_ADD>(a, acc, okn, basen, imgn, cob0, HW); break;
-    default: epilogue<MT, NT, EPI_GENERIC>(a, acc, okn, basen, imgn, cob0, HW); break;
-  }
+  epilogue<MT, NT, EPI_GENERIC>(a, acc, okn, basen, imgn, cob0, HW);
 }
 
 template <int MT, int NT>
-int launch_sb(const X3SbArgs& p, size_t lds, dim3 grid, hipStream_t st) {
-  (void)hipFuncSetAttribute((const void*)k_conv3x3_x3_sb<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_conv3x3_x3_sb<MT, NT>), grid, dim3(NTHR), lds, st, p);
+int launch_sb(const X3SbArgs& p, int VW, size_t lds, dim3 grid, hipStream_t st) {
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, st, p);
+  };
+  if (VW == 4) go(k_conv3x3_x3_sb<MT, NT, 4>);
+  else if (VW == 2) go(k_conv3x3_x3_sb<MT, NT, 2>);
+  else go(k_conv3x3_x3_sb<MT, NT, 1>);
   return check_launch("fdet_conv3x3_bf16x3(sb)");
 }
 
@@ -212,7 +351,9 @@ int launch_sb(const X3SbArgs& p, size_t lds, dim3 grid, hipStream_t st) {
 // Returns 1 when this kernel family has no tiling for the shape (the caller then uses the general
 // persistent kernel), else the launch status.  `a` arrives with N/Cin/Cout/H/W, pointers, dgrad, slope set.
 int fdet_x3_sb_run(ConvArgs a, hipStream_t st) {
-  a.WP = a.W + 1;
+  a.WP = (a.W + 1 + 3) / 4 * 4;           // pitch % 4 == 0: a quad of positions never straddles two rows
+  auto aligned = [](const void* q, size_t b) { return ((uintptr_t)q % b) == 0; };
+  const int VW = (a.W % 4 == 0 && aligned(a.x, 16)) ? 4 : ((a.W % 2 == 0 && aligned(a.x, 8)) ? 2 : 1);
   a.VR = a.N * (a.H + 1) + 1;
   if (a.VR >= (1 << 20) || (size_t)a.N * std::max(a.Cin, a.Cout) * a.H * a.W >= (size_t)1 << 31) return 1;
   a.CoP = (a.Cout + 31) / 32 * 32;
@@ -235,7 +376,7 @@ int fdet_x3_sb_run(ConvArgs a, hipStream_t st) {
       if (a.WP > cap) continue;
       int R = cap / a.WP;
       if (R > rows_total) R = rows_total;
-      if (2 * (R + 2) * a.W > nbs_of(NT) * NTHR) continue;
+      if (2 * (R + 2) * (a.W / VW) > nbs_of(NT, VW) * NTHR) continue;
       const int PT = cap + 2 * a.WP + 3;
       const size_t lds = (size_t)(2 * 9 * 2 * MT * 32 + 4 * PT) * 16;
       if (lds > 80 * 1024) continue;
@@ -253,16 +394,16 @@ int fdet_x3_sb_run(ConvArgs a, hipStream_t st) {
   a.magic_h1 = magic_of(a.H + 1);
   X3SbArgs p;
   p.PT = cap + 2 * a.WP + 3;
-  p.p_in = (a.R + 2) * a.W;
-  p.magic_w = magic_of(a.W);
+  p.p_in = (a.R + 2) * (a.W / VW);
+  p.magic_w = magic_of(a.W / VW);
   const size_t units = (size_t)(a.Cin / 16) * 9 * 2 * a.CoP;       // per hi / lo half
   p.a_hi = reinterpret_cast<const bf16x8*>(a.wpk);
   p.a_lo = p.a_hi + units;
   p.c = a;
   const size_t lds = (size_t)(2 * 9 * 2 * MT * 32 + 4 * p.PT) * 16;
   dim3 grid(a.nbands, a.CoP / (MT * 32));
-  if (MT == 2 && NT == 2) return launch_sb<2, 2>(p, lds, grid, st);
-  if (MT == 2 && NT == 1) return launch_sb<2, 1>(p, lds, grid, st);
-  if (MT == 1 && NT == 2) return launch_sb<1, 2>(p, lds, grid, st);
-  return launch_sb<1, 1>(p, lds, grid, st);
+  if (MT == 2 && NT == 2) return launch_sb<2, 2>(p, VW, lds, grid, st);
+  if (MT == 2 && NT == 1) return launch_sb<2, 1>(p, VW, lds, grid, st);
+  if (MT == 1 && NT == 2) return launch_sb<1, 2>(p, VW, lds, grid, st);
+  return launch_sb<1, 1>(p, VW, lds, grid, st);
 }
