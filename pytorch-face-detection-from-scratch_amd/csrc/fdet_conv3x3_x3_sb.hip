@@ -17,6 +17,7 @@ constexpr int CK16 = 16;     // input channels per chunk (= MFMA K)
 __host__ __device__ constexpr int nbs_of(int nt, int vw) { return vw == 4 ? 1 : (vw == 2 ? 2 : 3); }
 
 struct X3SbArgs {
+  int ntiles, ncob;            // persistent: tiles = nbands * ncob, walked with stride gridDim.x
   ConvArgs c;                // x, bias, epilogue pointers, geometry (WP, R, VR, nbands, mode ...)
   const bf16x8* a_hi;        // [Cin/16][9][2][CoP] x 8 bf16
   const bf16x8* a_lo;
@@ -90,78 +91,65 @@ __device__ __forceinline__ void epilogue_sb(const ConvArgs& a, f32x16 (&acc)[MT]
     img[n] = ok ? im : 0;
     idx0[n] = (ok ? ((im * a.Cout) * a.H + oy) * a.W + ox : 0) + (cob0 + 4 * half + j) * HW;   // + (32m + 8g)*HW
   }
-  // transposed accumulators: t[m][n][g][i] = channel cob0 + 32m + 8g + 4half + j, position q4 + i
-  f32x4 t[MT][NT][4], u[HAS_LD ? MT : 1][HAS_LD ? NT : 1][4];
+  float bz[MT][4];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int g = 0; g < 4; ++g) bz[m][g] = FWD ? g_bias[cob0 + 32 * m + 8 * g + 4 * half + j] : 0.f;
+  // one 32-position block (n) at a time: transposed accumulators t[m][g][i] = channel
+  // cob0 + 32m + 8g + 4half + j at position q4 + i; loads of the block, arithmetic, stores
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    f32x4 t[MT][4], u[MT][4];
+    float sc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float v_[4] = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
         quad_transpose4(v_, b0, b1);
-        t[m][n][g] = f32x4{v_[0], v_[1], v_[2], v_[3]};
+        t[m][g] = f32x4{v_[0], v_[1], v_[2], v_[3]};
+        u[m][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sc[m][g] = MODE == EPI_FWD_BOTH ? g_scale[img[n] * a.Cout + cob0 + 32 * m + 8 * g + 4 * half + j] : 1.f;
       }
-  float bz[MT][4], sc[MT][NT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int ch = cob0 + 32 * m + 8 * g + 4 * half + j;
-      bz[m][g] = FWD ? g_bias[ch] : 0.f;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) sc[m][n][g] = MODE == EPI_FWD_BOTH ? g_scale[img[n] * a.Cout + ch] : 1.f;
-    }
 #define SB_LD(BYTES)                                                                               \
   _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int g = 0; g < 4; ++g)     \
-    __builtin_memcpy(&u[m][n][g], src + idx0[n] + (32 * m + 8 * g) * HW, BYTES);
-  if (HAS_LD) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) u[m][n][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_memcpy(&u[m][g], src + idx0[n] + (32 * m + 8 * g) * HW, BYTES);
+    if (HAS_LD) {
       if (nv[n] == 4) { SB_LD(16) } else if (nv[n] == 3) { SB_LD(12) } else if (nv[n] == 2) { SB_LD(8) } else if (nv[n] == 1) { SB_LD(4) }
     }
-  }
 #undef SB_LD
-  // arithmetic for every lane (t <- value for y_full / dx, u <- value for y_out)
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float z = t[m][n][g][i];
+          float z = t[m][g][i];
           if (FWD) {
             const float w_ = z + bz[m][g];
             z = w_ > 0.f ? w_ : w_ * a.slope;
-            if (MODE == EPI_FWD_BOTH) u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i] = z * sc[m][n][g] + u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i];
-            if (MODE == EPI_FWD_OUT) u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i] = z + u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i];
+            if (MODE == EPI_FWD_BOTH) u[m][g][i] = z * sc[m][g] + u[m][g][i];
+            if (MODE == EPI_FWD_OUT) u[m][g][i] = z + u[m][g][i];
           } else if (MODE == EPI_DGRAD_ACT) {
-            z *= (u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i] > 0.f) ? 1.f : a.slope;
+            z *= (u[m][g][i] > 0.f) ? 1.f : a.slope;
           } else {
-            z += u[HAS_LD ? m : 0][HAS_LD ? n : 0][g][i];
+            z += u[m][g][i];
           }
-          t[m][n][g][i] = z;
+          t[m][g][i] = z;
         }
 #define SB_ST(BYTES)                                                                               \
   _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int g = 0; g < 4; ++g) {   \
     const int idx_ = idx0[n] + (32 * m + 8 * g) * HW;                                              \
-    if (MODE != EPI_FWD_OUT) __builtin_memcpy(g_full + idx_, &t[m][n][g], BYTES);                  \
-    if (MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT) __builtin_memcpy(g_out + idx_, &u[HAS_LD ? m : 0][HAS_LD ? n : 0][g], BYTES); \
+    if (MODE != EPI_FWD_OUT) __builtin_memcpy(g_full + idx_, &t[m][g], BYTES);                     \
+    if (MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT) __builtin_memcpy(g_out + idx_, &u[m][g], BYTES); \
   }
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
     if (nv[n] == 4) { SB_ST(16) } else if (nv[n] == 3) { SB_ST(12) } else if (nv[n] == 2) { SB_ST(8) } else if (nv[n] == 1) { SB_ST(4) }
-  }
 #undef SB_ST
+  }
 }
 
-template <int MT, int NT, int VW>
+template <int MT, int NT, int VW, int MODE>
 __global__ void __launch_bounds__(NTHR, 2)
 k_conv3x3_x3_sb(const X3SbArgs p) {
   constexpr int NBS = nbs_of(NT, VW);
@@ -176,8 +164,9 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
   bf16x8* lds = reinterpret_cast<bf16x8*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int band = blockIdx.x, mb = blockIdx.y;
-  const int v0 = band * a.R;
+  int tile = blockIdx.x;
+  int mb = tile % p.ncob;
+  int v0 = (tile / p.ncob) * a.R;
   const int H1 = a.H + 1;
   const size_t HW = (size_t)a.H * a.W;
 
@@ -186,26 +175,31 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     for (int t = tid; t < buf_units; t += NTHR) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // ---- B staging geometry (chunk invariant): slot -> (k-half, tile row, column)
-  int b_src[NBS], b_dst[NBS];                         // src: element offset for channel 8h of chunk 0 (-1: skip)
+  // ---- B staging geometry: slot -> (k-half, tile row, column); the source depends on the tile
+  int b_tr[NBS], b_xo[NBS], b_dst[NBS], b_src[NBS];   // b_tr < 0: no item; b_src < 0: row outside the batch (zeros)
 #pragma unroll
   for (int s = 0; s < NBS; ++s) {
     const int it = s * NTHR + tid;
-    b_src[s] = -1; b_dst[s] = 0;
+    b_tr[s] = -1; b_xo[s] = 0; b_dst[s] = 0; b_src[s] = -1;
     if (it < 2 * p.p_in) {
       const int h = it >= p.p_in ? 1 : 0;
       const int pp = it - h * p.p_in;
       const int tr = fdiv(pp, p.magic_w), ix = (pp - tr * (a.W / VW)) * VW;
-      const int v = v0 - 1 + tr;
-      if (v >= 0 && v < a.VR) {
-        const int n = fdiv(v, a.magic_h1), yy = v - n * H1 - 1;
-        if (yy >= 0) {
-          b_src[s] = ((n * a.Cin + 8 * h) * a.H + yy) * a.W + ix;
-          b_dst[s] = h * PT + tr * WP + 1 + ix;       // unit index inside the hi array pair; lo = +2*PT
-        }
-      }
+      b_tr[s] = tr;
+      b_xo[s] = 8 * h * a.H * a.W + ix;
+      b_dst[s] = h * PT + tr * WP + 1 + ix;           // unit index inside the hi array pair; lo = +2*PT
     }
   }
+#define X3_TILE_SRC(V0)                                                                            \
+  {                                                                                                \
+    _Pragma("unroll") for (int s_ = 0; s_ < NBS; ++s_) {                                           \
+      const int v_ = (V0) - 1 + b_tr[s_];                                                          \
+      const int n_ = fdiv(max(v_, 0), a.magic_h1), yy_ = v_ - n_ * H1 - 1;                         \
+      const bool ok_ = b_tr[s_] >= 0 && v_ >= 0 && v_ < a.VR && yy_ >= 0;                          \
+      b_src[s_] = ok_ ? (n_ * a.Cin * a.H + yy_) * a.W + b_xo[s_] : -1;                            \
+    }                                                                                              \
+  }
+  X3_TILE_SRC(v0)
   const int a_chunk_units = 9 * 2 * a.CoP;            // units per chunk per array in HBM
   bf16x8 pa[NA];
   VT pb[NBS][8];
@@ -234,10 +228,10 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     }                                                                                              \
     bf16x8* B_ = buf_ + 2 * A_UNITS;                                                               \
     _Pragma("unroll") for (int s_ = 0; s_ < NBS; ++s_) {                                           \
-      if (b_src[s_] >= 0) {                                                                        \
+      if (b_tr[s_] >= 0) {                                                                         \
         _Pragma("unroll") for (int i_ = 0; i_ < VW; ++i_) {                                        \
           float f_[8];                                                                             \
-          _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) f_[j_] = vget<VW>(pb[s_][j_], i_);      \
+          _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) f_[j_] = b_src[s_] >= 0 ? vget<VW>(pb[s_][j_], i_) : 0.f; \
           bf16x8 hi_, lo_;                                                                         \
           split8(f_, hi_, lo_);                                                                    \
           B_[b_dst[s_] + i_] = hi_;                                                                \
@@ -267,12 +261,25 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
   __syncthreads();                       // zero fill complete
 
   const int nch = a.Cin / CK16;
+  bool first = true;
+  for (; tile < p.ntiles; tile += gridDim.x) {
+  const int cur_v0 = v0, cur_mb = mb;    // the tile whose chunks are consumed below
   for (int c = 0; c < nch; ++c) {
     const bf16x8* buf = lds;
-    if (c > 0) __syncthreads();          // every wave is done reading chunk c-1
+    if (!first) __syncthreads();         // every wave is done reading the previous chunk
+    first = false;
     X3_WRITE_LDS(lds)
     __syncthreads();
-    if (c + 1 < nch) X3_ISSUE_LOADS(c + 1)
+    if (c + 1 < nch) {
+      X3_ISSUE_LOADS(c + 1)
+    } else if (tile + (int)gridDim.x < p.ntiles) {
+      // the next tile's first chunk travels during this tile's last MFMA block and its epilogue
+      const int nt_ = tile + gridDim.x;
+      mb = nt_ % p.ncob;
+      v0 = (nt_ / p.ncob) * a.R;
+      X3_TILE_SRC(v0)
+      X3_ISSUE_LOADS(0)
+    }
     const bf16x8* Aw = buf + a_off;
     const bf16x8* Bw = buf + b_off;
     // one fragment set: while this wave waits for its LDS reads the partner wave of the other
@@ -307,31 +314,32 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
 
   // ---- epilogue: fast modes through the quad transpose (16-byte accesses), GENERIC through the
   //      channel-per-register epilogue shared with the fp32 kernel
-  const int cob0_t = mb * MB;
-  switch (a.mode) {
-    case EPI_FWD_FULL: epilogue_sb<MT, NT, EPI_FWD_FULL>(a, acc, v0, qwave, cob0_t, l31, half); return;
-    case EPI_FWD_BOTH: epilogue_sb<MT, NT, EPI_FWD_BOTH>(a, acc, v0, qwave, cob0_t, l31, half); return;
-    case EPI_FWD_OUT: epilogue_sb<MT, NT, EPI_FWD_OUT>(a, acc, v0, qwave, cob0_t, l31, half); return;
-    case EPI_DGRAD_ACT: epilogue_sb<MT, NT, EPI_DGRAD_ACT>(a, acc, v0, qwave, cob0_t, l31, half); return;
-    case EPI_DGRAD_ADD: epilogue_sb<MT, NT, EPI_DGRAD_ADD>(a, acc, v0, qwave, cob0_t, l31, half); return;
-    default: break;
-  }
-  const int qlimit = a.R * WP;
-  bool okn[NT];
-  size_t basen[NT];
-  int imgn[NT];
+  if (MODE != EPI_GENERIC) {
+    epilogue_sb<MT, NT, MODE>(a, acc, cur_v0, qwave, cur_mb * MB, l31, half);
+  } else {
+    const int qlimit = a.R * WP;
+    bool okn[NT];
+    size_t basen[NT];
+    int imgn[NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int q = qwave + n * 32 + l31;
-    const int tr = q / WP, ox = q - tr * WP;
-    const int v = v0 + tr;
-    const int img = v / H1, oy = v - img * H1 - 1;
-    okn[n] = (q < qlimit) && (ox < a.W) && (v < a.VR) && (oy >= 0);
-    basen[n] = ((size_t)img * a.Cout * a.H + oy) * a.W + ox;
-    imgn[n] = img;
+    for (int n = 0; n < NT; ++n) {
+      const int q = qwave + n * 32 + l31;
+      const int tr = q / WP, ox = q - tr * WP;
+      const int v = cur_v0 + tr;
+      const int img = v / H1, oy = v - img * H1 - 1;
+      okn[n] = (q < qlimit) && (ox < a.W) && (v < a.VR) && (oy >= 0);
+      basen[n] = ((size_t)img * a.Cout * a.H + oy) * a.W + ox;
+      imgn[n] = img;
+    }
+    epilogue<MT, NT, EPI_GENERIC>(a, acc, okn, basen, imgn, cur_mb * MB + 4 * half, HW);
   }
-  const int cob0 = mb * MB + 4 * half;
-  epilogue<MT, NT, EPI_GENERIC>(a, acc, okn, basen, imgn, cob0, HW);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  }                                      // tile loop
 }
 
 template <int MT, int NT>
@@ -340,9 +348,17 @@ int launch_sb(const X3SbArgs& p, int VW, size_t lds, dim3 grid, hipStream_t st) 
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, st, p);
   };
-  if (VW == 4) go(k_conv3x3_x3_sb<MT, NT, 4>);
-  else if (VW == 2) go(k_conv3x3_x3_sb<MT, NT, 2>);
-  else go(k_conv3x3_x3_sb<MT, NT, 1>);
+#define SB_MODES(V_)                                                                               \
+  switch (p.c.mode) {                                                                              \
+    case EPI_FWD_FULL: go(k_conv3x3_x3_sb<MT, NT, V_, EPI_FWD_FULL>); break;                       \
+    case EPI_FWD_BOTH: go(k_conv3x3_x3_sb<MT, NT, V_, EPI_FWD_BOTH>); break;                       \
+    case EPI_FWD_OUT: go(k_conv3x3_x3_sb<MT, NT, V_, EPI_FWD_OUT>); break;                         \
+    case EPI_DGRAD_ACT: go(k_conv3x3_x3_sb<MT, NT, V_, EPI_DGRAD_ACT>); break;                     \
+    case EPI_DGRAD_ADD: go(k_conv3x3_x3_sb<MT, NT, V_, EPI_DGRAD_ADD>); break;                     \
+    default: go(k_conv3x3_x3_sb<MT, NT, V_, EPI_GENERIC>); break;                                  \
+  }
+  if (VW == 4) { SB_MODES(4) } else if (VW == 2) { SB_MODES(2) } else { SB_MODES(1) }
+#undef SB_MODES
   return check_launch("fdet_conv3x3_bf16x3(sb)");
 }
 
@@ -370,8 +386,11 @@ int fdet_x3_sb_run(ConvArgs a, hipStream_t st) {
   }
   const int rows_total = a.VR - 1;
   int bestNT = 0, bestMT = 0, bestR = 0; double bestT = 0;
+  int forceMT = 0, forceNT = 0;
+  if (const char* e = getenv("FDET_SB_TILE")) sscanf(e, "%d,%d", &forceMT, &forceNT);
   for (int MT = (a.CoP % 64 == 0) ? 2 : 1; MT >= 1; --MT)
     for (int NT = 2; NT >= 1; NT >>= 1) {
+      if (forceMT && (MT != forceMT || NT != forceNT)) continue;
       const int cap = 4 * NT * 32;
       if (a.WP > cap) continue;
       int R = cap / a.WP;
@@ -401,7 +420,16 @@ int fdet_x3_sb_run(ConvArgs a, hipStream_t st) {
   p.a_lo = p.a_hi + units;
   p.c = a;
   const size_t lds = (size_t)(2 * 9 * 2 * MT * 32 + 4 * p.PT) * 16;
-  dim3 grid(a.nbands, a.CoP / (MT * 32));
+  p.ncob = a.CoP / (MT * 32);
+  p.ntiles = a.nbands * p.ncob;
+  // persistent: two workgroups per CU walk the tiles (the zero fill and the first-chunk latency are
+  // paid once per workgroup, later tiles prefetch their first chunk under the previous tile's tail)
+  int ncu = 256;
+  { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v; }
+  int gsz = 2 * ncu;
+  if (const char* e = getenv("FDET_SB_GRID")) gsz = atoi(e) > 0 ? atoi(e) : p.ntiles;
+  dim3 grid(p.ntiles < gsz ? p.ntiles : gsz, 1);
+  p.c.stagger = 0;
   if (MT == 2 && NT == 2) return launch_sb<2, 2>(p, VW, lds, grid, st);
   if (MT == 2 && NT == 1) return launch_sb<2, 1>(p, VW, lds, grid, st);
   if (MT == 1 && NT == 2) return launch_sb<1, 2>(p, VW, lds, grid, st);

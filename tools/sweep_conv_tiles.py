@@ -10,7 +10,7 @@ from fdet_amd import hotpath as hp
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 C = 64
-cfgs = [(8, 2, 0), (8, 2, 18000), (8, 2, 36000), (4, 4, 0), (4, 4, 36000), (8, 1, 0), (8, 1, 9000)]
+cfgs = [(2, 2, 0), (2, 1, 0), (1, 2, 0), (1, 1, 0)]
 
 
 def timeit(fn, reps=10):
@@ -31,13 +31,13 @@ for H in (60, 30, 15):
     wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda"); hp.pack_conv3x3_weights(w, wf, wb, x3=True)
     ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x[:8], w, b, padding=1), 0.2)
     for mt, nt, sb in cfgs:
-        os.environ["FDET_CONV_TILE"] = f"{mt},{nt}"
+        os.environ["FDET_SB_TILE"] = f"{mt},{nt}"
         os.environ["FDET_CONV_STAGGER"] = str(sb)
         try:
             t1 = timeit(lambda: hp.conv3x3_fwd(x, wf, b, C, y_full=y, x3=True))
             err = float((y[:8] - ref).abs().max())
             t2 = timeit(lambda: hp.conv3x3_dgrad(dz, wb, C, y2, act=x, x3=True))
-            print(f"H={H} NW={mt} NT={nt} stagger={sb}: fwd {t1*1e3:.1f} us  dgrad+act {t2*1e3:.1f} us  maxerr {err:.2e}", flush=True)
+            print(f"H={H} MT={mt} NT={nt} stagger={sb}: fwd {t1*1e3:.1f} us  dgrad+act {t2*1e3:.1f} us  maxerr {err:.2e}", flush=True)
         except Exception as ex:
-            print(f"H={H} NW={mt} NT={nt} stagger={sb}: {str(ex)[:120]}", flush=True)
+            print(f"H={H} MT={mt} NT={nt} stagger={sb}: {str(ex)[:120]}", flush=True)
 os.environ.pop("FDET_CONV_TILE", None); os.environ.pop("FDET_CONV_STAGGER", None)
