@@ -118,6 +118,31 @@ int fdet_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    int step, double lr, double beta1, double beta2, double eps, float grad_scale,
                    void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * SSD detection math (next row after the YOLO path; BASELINE.json config 4).  Priors are ordered
+ * (scale, i, j); h_patch_sizes is a HOST array (reference: (60,30,15,7) -> P = 4774).
+ * ------------------------------------------------------------------------------------- */
+int fdet_ssd_num_priors(const int* h_patch_sizes, int nscales);
+/* Multi-scale target encode: WIDERFaceDatasetSSD.convert_bbx_to_feature_map per scale + concat
+ * (datasets/WIDERFace/dataset_ssd.py:36-76,134-139).  boxes/box_offsets as fdet_encode_targets;
+ * out [B,P,5] rows [conf - 0.001*ps, off_x, off_y, w/W, h/H]. */
+int fdet_ssd_encode_targets(const float* boxes, const int32_t* box_offsets, int B, const int* h_patch_sizes,
+                            int nscales, float img_w, float img_h, float* out, void* stream);
+/* ssd_loss(y_hat[:,:,0], y_hat[:,:,1:], y[:,:,0], y[:,:,1:], neg_pos_ratio) and its autograd
+ * (losses/SSDLoss.py:25-86, models/ModelMetaSSD.py:127-129): per-image hard negative mining
+ * (rank of -log(conf) among the negatives, ties by index), BCE over positives + mined negatives
+ * with rounded labels, smooth-L1 over positives, divided by the batch's positive count.
+ *   pred/target [B,P,5]; loss [1]; grad [B,P,5] or NULL; mask [B,P] (1 = contributes) or NULL. */
+size_t fdet_ssd_loss_ws_bytes(int B);
+int fdet_ssd_loss_fwd_bwd(const float* pred, const float* target, int B, int P, int neg_pos_ratio, float* loss,
+                          float* grad, uint8_t* mask, void* ws, size_t ws_bytes, void* stream);
+/* ReduceSSDBoundingBoxes.forward for a batch (datasets/utils.py:54-92): decode (with_priors: scale by
+ * 1/ps and add the cell origin), threshold (strict >), xyxy, round half even, greedy NMS, xywh.
+ *   x [B,P,5]; out [B,P,5] rows [score,x,y,w,h] (first out_counts[n] rows valid). */
+int fdet_ssd_reduce_bounding_boxes(const float* x, int B, const int* h_patch_sizes, int nscales, int with_priors,
+                                   float prob_threshold, double iou_threshold, float img_w, float img_h,
+                                   float* out, int32_t* out_counts, void* stream);
+
 /* Bilinear Resize fused with the /255 normalisation: replaces `self.resize(x) / 255.0`
  * (models/PoolResnet.py:91,95; models/Resnet.py likewise) and `Resize(...)(x); x / 255.0`
  * (models/BaseModel.py:64-65), i.e. torchvision 0.11.2 transforms.Resize on tensors =

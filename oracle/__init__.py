@@ -14,3 +14,4 @@ arithmetic that is absent from ``/root/reference`` (``torchvision.ops.nms`` /
 parity is UNPINNED (no reference fixture exists) and the tests say so.
 """
 from .yolo_oracle import *  # noqa: F401,F403
+from . import ssd_oracle  # noqa: F401,E402  (SSD detection math, SURVEY.md 8f rank 2)

@@ -49,6 +49,11 @@ SIGNATURES = {
     "fdet_nms": (_I, [_P, _P, _P, _I, _I, _D, _P, _P, _P]),
     "fdet_reduce_bounding_boxes": (_I, [_P, _I, _I, _F, _D, _F, _F, _P, _P, _P]),
     "fdet_step_metrics": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "fdet_ssd_num_priors": (_I, [_P, _I]),
+    "fdet_ssd_encode_targets": (_I, [_P, _P, _I, _P, _I, _F, _F, _P, _P]),
+    "fdet_ssd_loss_ws_bytes": (_SZ, [_I]),
+    "fdet_ssd_loss_fwd_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "fdet_ssd_reduce_bounding_boxes": (_I, [_P, _I, _P, _I, _I, _F, _D, _F, _F, _P, _P, _P]),
     "fdet_u8_to_f32_norm": (_I, [_P, _P, _SZ, _P]),
     "fdet_resize_bilinear_u8_norm": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_resize_bilinear_f32_norm": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),

@@ -313,8 +313,8 @@ extern "C" int fdet_decode(const float* maps, int B, int S, float prob_threshold
 
 extern "C" int fdet_nms(const float* boxes, const float* scores, const int32_t* counts, int B, int Kmax,
                         double iou_threshold, int32_t* keep, int32_t* keep_counts, void* stream) {
-  FDET_REQUIRE(B > 0 && Kmax > 0 && Kmax <= 4096 && boxes && scores && counts && keep && keep_counts,
-               "nms: bad arguments (Kmax=%d must be in 1..4096)", Kmax);
+  FDET_REQUIRE(B > 0 && Kmax > 0 && Kmax <= 4864 && boxes && scores && counts && keep && keep_counts,
+               "nms: bad arguments (Kmax=%d must be in 1..4864: 33 bytes of LDS per candidate)", Kmax);
   const size_t lds = nms_lds_bytes(Kmax) + (size_t)Kmax * 4;
   if (int rc = set_lds(k_nms, lds)) return rc;
   hipLaunchKernelGGL(k_nms, dim3(B), dim3(256), lds, (hipStream_t)stream, boxes, scores, counts, Kmax,
@@ -430,6 +430,300 @@ extern "C" int fdet_u8_to_f32_norm(const uint8_t* in, float* out, size_t n, void
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(k_u8_norm, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, n);
   return check_launch("fdet_u8_to_f32_norm");
+}
+
+// ======================================================================================
+// SSD detection math (BASELINE.json config 4: "anchor match + hard-neg mining")
+//   multi-scale target encode   datasets/WIDERFace/dataset_ssd.py:36-76,134-139
+//   ssd_loss + hard negative mining (+ autograd)   losses/SSDLoss.py:7-86, models/ModelMetaSSD.py:127-129
+//   ReduceSSDBoundingBoxes      datasets/utils.py:8-92
+// Priors are ordered (scale, i, j); P = sum ps^2 (4774 for 60/30/15/7).
+// ======================================================================================
+constexpr int SSD_MAXS = 8;
+struct SsdScales { int n; int ps[SSD_MAXS]; int start[SSD_MAXS + 1]; };
+
+__global__ void __launch_bounds__(256)
+k_ssd_encode(const float* __restrict__ boxes, const int32_t* __restrict__ offs, const SsdScales sc, float fw, float fh,
+             float* __restrict__ out) {
+  const int n = blockIdx.x, P = sc.start[sc.n];
+  float* o = out + (size_t)n * P * 5;
+  for (int t = threadIdx.x; t < P * 5; t += blockDim.x) o[t] = 0.f;
+  __syncthreads();
+  if (threadIdx.x < sc.n) {                                          // one thread per scale: later boxes overwrite
+    const int ps = sc.ps[threadIdx.x];
+    const float xps = (float)(1.0 / ps);                             // python float 1/ps, used as an fp32 scalar
+    const float dconf = (float)(0.001 * ps);
+    for (int k = offs[n]; k < offs[n + 1]; ++k) {
+      const float* b = boxes + (size_t)k * 5;
+      const float xn = b[1] / fw, yn = b[2] / fh, wn = b[3] / fw, hn = b[4] / fh;   // :44-45
+      int i = (int)floor((double)(xn / xps)), j = (int)floor((double)(yn / xps));  // :54
+      float v1 = xn - (float)((double)i * (1.0 / ps));               // :65
+      float v2 = yn - (float)((double)j * (1.0 / ps));
+      v1 = v1 / xps; v2 = v2 / xps;                                  // :69-70
+      i = min(max(i, 0), ps - 1); j = min(max(j, 0), ps - 1);        // :75-76
+      float* d = o + (size_t)(sc.start[threadIdx.x] + i * ps + j) * 5;
+      d[0] = b[0] - dconf; d[1] = v1; d[2] = v2; d[3] = wn; d[4] = hn;
+    }
+  }
+}
+
+// one workgroup per image: mining mask, loss partials, un-normalised gradients
+__global__ void __launch_bounds__(256)
+k_ssd_loss_image(const float* __restrict__ pred, const float* __restrict__ tgt, int P, int ratio,
+                 float* __restrict__ grad, unsigned char* __restrict__ mask_out, double* __restrict__ part /*[B][3]*/) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_loss = reinterpret_cast<float*>(smem);                    // -log(conf); -inf for positives
+  __shared__ double s_red[3][4];
+  __shared__ int s_npos;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* pr = pred + (size_t)n * P * 5;
+  const float* tg = tgt + (size_t)n * P * 5;
+  if (tid == 0) s_npos = 0;
+  __syncthreads();
+  int cnt = 0;
+  for (int i = tid; i < P; i += 256) {
+    const bool pos = tg[(size_t)i * 5] > 0.f;                        // SSDLoss.py:39
+    cnt += pos;
+    s_loss[i] = pos ? -INFINITY : -logf(pr[(size_t)i * 5]);          // :45, :68
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if (lane == 0) atomicAdd(&s_npos, cnt);
+  __syncthreads();
+  const int npos = s_npos;
+  const long long nneg = (long long)npos * ratio;                    // :43
+  // ---- the nneg largest losses among the negatives (descending sort, ties: lower index first;
+  //      :46-52) by radix select on the order-preserving integer image of the floats: four 8-bit
+  //      passes find the threshold key T, then keys > T are in and keys == T fill the rest in index order
+  const int P_neg = P - npos;
+  const long long kk = nneg < (long long)P_neg ? nneg : (long long)P_neg;   // negatives to keep
+  __shared__ int s_hist[256];
+  __shared__ unsigned s_prefix, s_mask;
+  __shared__ int s_want, s_tiebase[5];
+  auto key_of = [&](int i) -> unsigned {
+    const unsigned b = __float_as_uint(s_loss[i]);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);               // monotone: larger float -> larger key
+  };
+  if (tid == 0) { s_prefix = 0u; s_mask = 0u; s_want = (int)kk; }
+  __syncthreads();
+  if (kk > 0 && kk < P_neg) {
+    for (int pass = 3; pass >= 0; --pass) {
+      for (int t = tid; t < 256; t += 256) s_hist[t] = 0;
+      __syncthreads();
+      const unsigned prefix = s_prefix, msk = s_mask;
+      for (int i = tid; i < P; i += 256) {
+        if (s_loss[i] == -INFINITY && tg[(size_t)i * 5] > 0.f) continue;         // positives are not candidates
+        const unsigned k = key_of(i);
+        if ((k & msk) == prefix) atomicAdd(&s_hist[(k >> (8 * pass)) & 255u], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int want = s_want, b = 255;
+        for (; b > 0; --b) { if (s_hist[b] >= want) break; want -= s_hist[b]; }
+        s_want = want;                                               // rank inside the chosen bin (1-based count still to take)
+        s_prefix = prefix | ((unsigned)b << (8 * pass));
+        s_mask = msk | (0xFFu << (8 * pass));
+      }
+      __syncthreads();
+    }
+  }
+  const unsigned Tkey = s_prefix;                                    // threshold key (valid when 0 < kk < P_neg)
+  const int ties_to_take = s_want;                                   // how many keys == T are kept (lowest indices)
+  __syncthreads();
+  double bce = 0.0, sl1 = 0.0;
+  int tie_seen_base = 0;                                             // ties with a lower index in earlier sweeps
+  for (int i0 = 0; i0 < P; i0 += 256) {
+    const int i = i0 + tid;
+    const bool inb = i < P;
+    const float label = inb ? tg[(size_t)i * 5] : 0.f;
+    const bool pos = inb && label > 0.f;
+    bool sel = pos;
+    bool tie = false;
+    if (inb && !pos) {
+      if (kk >= P_neg) sel = kk > 0;
+      else if (kk > 0) { const unsigned k = key_of(i); sel = k > Tkey; tie = k == Tkey; }
+    }
+    // ordered count of the ties in this sweep (index order = lane order inside the sweep)
+    const unsigned long long bal = __ballot(tie);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_tiebase[1 + wid] = __popcll(bal);
+    __syncthreads();
+    int base = tie_seen_base;
+    for (int w = 0; w < wid; ++w) base += s_tiebase[1 + w];
+    if (tie) sel = base + before < ties_to_take;
+    tie_seen_base += s_tiebase[1] + s_tiebase[2] + s_tiebase[3] + s_tiebase[4];
+    __syncthreads();
+    if (!inb) continue;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+    if (sel) {
+      const float c0 = pr[(size_t)i * 5];
+      const float lo = 1e-7f, hi = 1.f - 1e-7f;                      // 10**-7 as an fp32 scalar (:13-14)
+      const float c = fminf(fmaxf(c0, lo), hi);
+      const float lr = rintf(label);                                 // :72
+      bce += (double)(-1.f * (lr * logf(c) + (1.f - lr) * logf(1.f - c)));
+      if (c0 >= lo && c0 <= hi) g0 = -(lr / c) + (1.f - lr) / (1.f - c);
+    }
+    if (pos) {
+      const float* pl = pr + (size_t)i * 5 + 1;
+      const float* gl = tg + (size_t)i * 5 + 1;
+      float gg[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = pl[k] - gl[k], ad = fabsf(d);
+        sl1 += ad < 1.f ? (double)(0.5f * d * d) : (double)(ad - 0.5f);           // F.smooth_l1_loss, beta = 1
+        gg[k] = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+      }
+      g1 = gg[0]; g2 = gg[1]; g3 = gg[2]; g4 = gg[3];
+    }
+    if (grad) {
+      float* go = grad + ((size_t)n * P + i) * 5;
+      go[0] = g0; go[1] = g1; go[2] = g2; go[3] = g3; go[4] = g4;
+    }
+    if (mask_out) mask_out[(size_t)n * P + i] = sel ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) { bce += __shfl_down(bce, off, 64); sl1 += __shfl_down(sl1, off, 64); }
+  if (lane == 0) { s_red[0][wid] = bce; s_red[1][wid] = sl1; }
+  __syncthreads();
+  if (tid == 0) {
+    part[(size_t)n * 3 + 0] = ((s_red[0][0] + s_red[0][1]) + s_red[0][2]) + s_red[0][3];
+    part[(size_t)n * 3 + 1] = ((s_red[1][0] + s_red[1][1]) + s_red[1][2]) + s_red[1][3];
+    part[(size_t)n * 3 + 2] = (double)npos;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_ssd_loss_total(const double* __restrict__ part, int B, float* __restrict__ loss, float* __restrict__ inv_npos) {
+  if (threadIdx.x == 0) {
+    double bce = 0.0, sl1 = 0.0, np = 0.0;
+    for (int n = 0; n < B; ++n) { bce += part[n * 3]; sl1 += part[n * 3 + 1]; np += part[n * 3 + 2]; }
+    loss[0] = (float)((sl1 + bce) / np);                             // :86 (0/0 = NaN as in the reference)
+    inv_npos[0] = (float)(1.0 / np);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_ssd_scale_grad(float* __restrict__ grad, size_t n, const float* __restrict__ inv_npos) {
+  const float s = inv_npos[0];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) grad[i] *= s;
+}
+
+// one workgroup per image: decode with priors -> threshold -> round -> greedy NMS -> xywh
+__global__ void __launch_bounds__(256)
+k_ssd_reduce(const float* __restrict__ x, const SsdScales sc, int with_priors, float pt, double thr, float fw, float fh,
+             float* __restrict__ out, int32_t* __restrict__ out_counts) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = blockIdx.x, P = sc.start[sc.n];
+  NmsLds L = carve(smem, P);
+  int* s_base = reinterpret_cast<int*>(smem + nms_lds_bytes(P) - 64);
+  int* keep_idx = reinterpret_cast<int*>(smem + nms_lds_bytes(P));
+  const float* m = x + (size_t)n * P * 5;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  if (tid == 0) s_base[0] = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < P; c0 += blockDim.x) {                        // ordered compaction (utils.py:54-59)
+    const int c = c0 + tid;
+    const bool hit = (c < P) && (m[(size_t)c * 5] > pt);
+    const unsigned long long bal = __ballot(hit);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_base[1 + wid] = __popcll(bal);
+    __syncthreads();
+    int base = s_base[0];
+    for (int w = 0; w < wid; ++w) base += s_base[1 + w];
+    if (hit) {
+      const int k = base + before;
+      int s_ = 0;
+      while (s_ + 1 < sc.n && c >= sc.start[s_ + 1]) ++s_;
+      const int ps = sc.ps[s_], loc = c - sc.start[s_];
+      const int i = loc / ps, j = loc - i * ps;
+      const float* r = m + (size_t)c * 5;
+      float v1 = r[1], v2 = r[2];
+      if (with_priors) {                                             // :63-68
+        const float mult = (float)(1.0 / ps);
+        v1 = v1 * mult; v2 = v2 * mult;
+        v1 = v1 + (float)i * mult; v2 = v2 + (float)j * mult;
+      }
+      const float X = v1 * fw, Y = v2 * fh, Wd = r[3] * fw, Hd = r[4] * fh;       // :69-70 (width, height as named there)
+      const float X2 = Wd + X, Y2 = Hd + Y;                          // :79-80
+      L.score[k] = r[0];
+      L.x1[k] = rintf(X); L.y1[k] = rintf(Y); L.x2[k] = rintf(X2); L.y2[k] = rintf(Y2);   // :84
+    }
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < nw; ++w) t += s_base[1 + w]; s_base[0] += t; }
+    __syncthreads();
+  }
+  const int K = s_base[0];
+  __syncthreads();
+  const int nk = nms_lds(L, K, thr, keep_idx, s_base);
+  for (int k = tid; k < nk; k += blockDim.x) {
+    const int i = keep_idx[k];
+    float* o = out + ((size_t)n * P + k) * 5;
+    o[0] = L.score[i]; o[1] = L.x1[i]; o[2] = L.y1[i];
+    o[3] = L.x2[i] - L.x1[i];                                        // :73-74
+    o[4] = L.y2[i] - L.y1[i];
+  }
+  if (tid == 0) out_counts[n] = nk;
+}
+
+static int ssd_scales(const int* h_ps, int ns, SsdScales& sc) {
+  if (!h_ps || ns < 1 || ns > SSD_MAXS) return fail(FDET_EINVAL, "ssd: 1..%d patch sizes (got %d)", SSD_MAXS, ns);
+  sc.n = ns; sc.start[0] = 0;
+  for (int s = 0; s < ns; ++s) {
+    if (h_ps[s] < 1 || h_ps[s] > 1024) return fail(FDET_EINVAL, "ssd: bad patch size %d", h_ps[s]);
+    sc.ps[s] = h_ps[s]; sc.start[s + 1] = sc.start[s] + h_ps[s] * h_ps[s];
+  }
+  return FDET_OK;
+}
+
+extern "C" int fdet_ssd_num_priors(const int* h_patch_sizes, int nscales) {
+  SsdScales sc{};
+  if (ssd_scales(h_patch_sizes, nscales, sc)) return -1;
+  return sc.start[sc.n];
+}
+
+extern "C" int fdet_ssd_encode_targets(const float* boxes, const int32_t* box_offsets, int B, const int* h_patch_sizes,
+                                       int nscales, float img_w, float img_h, float* out, void* stream) {
+  FDET_REQUIRE(boxes && box_offsets && out && B > 0 && img_w > 0 && img_h > 0, "ssd_encode_targets: bad arguments");
+  SsdScales sc{};
+  if (int rc = ssd_scales(h_patch_sizes, nscales, sc)) return rc;
+  hipLaunchKernelGGL(k_ssd_encode, dim3(B), dim3(256), 0, (hipStream_t)stream, boxes, box_offsets, sc, img_w, img_h, out);
+  return check_launch("fdet_ssd_encode_targets");
+}
+
+extern "C" size_t fdet_ssd_loss_ws_bytes(int B) { return B > 0 ? (size_t)B * 3 * sizeof(double) + 16 : 0; }
+
+extern "C" int fdet_ssd_loss_fwd_bwd(const float* pred, const float* target, int B, int P, int neg_pos_ratio, float* loss,
+                                     float* grad, uint8_t* mask, void* ws, size_t ws_bytes, void* stream) {
+  FDET_REQUIRE(pred && target && loss && ws && B > 0 && P > 0 && neg_pos_ratio >= 0, "ssd_loss_fwd_bwd: bad arguments");
+  FDET_REQUIRE((size_t)P * 4 <= 150 * 1024, "ssd_loss_fwd_bwd: P=%d priors exceed the LDS tile", P);
+  if (ws_bytes < fdet_ssd_loss_ws_bytes(B)) return fail(FDET_EWORKSPACE, "ssd_loss_fwd_bwd: workspace %zu < %zu bytes", ws_bytes, fdet_ssd_loss_ws_bytes(B));
+  double* part = (double*)ws;
+  float* inv = (float*)(part + (size_t)B * 3);
+  const size_t lds = (size_t)P * 4;
+  if (int rc = set_lds(k_ssd_loss_image, lds)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_ssd_loss_image, dim3(B), dim3(256), lds, st, pred, target, P, neg_pos_ratio, grad, mask, part);
+  if (int rc = check_launch("fdet_ssd_loss_fwd_bwd")) return rc;
+  hipLaunchKernelGGL(k_ssd_loss_total, dim3(1), dim3(64), 0, st, part, B, loss, inv);
+  if (grad) {
+    const size_t n = (size_t)B * P * 5;
+    size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_ssd_scale_grad, dim3((unsigned)blocks), dim3(256), 0, st, grad, n, inv);
+  }
+  return check_launch("fdet_ssd_loss_fwd_bwd(total)");
+}
+
+extern "C" int fdet_ssd_reduce_bounding_boxes(const float* x, int B, const int* h_patch_sizes, int nscales, int with_priors,
+                                              float prob_threshold, double iou_threshold, float img_w, float img_h,
+                                              float* out, int32_t* out_counts, void* stream) {
+  FDET_REQUIRE(x && out && out_counts && B > 0, "ssd_reduce_bounding_boxes: bad arguments");
+  SsdScales sc{};
+  if (int rc = ssd_scales(h_patch_sizes, nscales, sc)) return rc;
+  const int P = sc.start[sc.n];
+  const size_t lds = nms_lds_bytes(P) + (size_t)P * 4;
+  FDET_REQUIRE(lds <= 160 * 1024, "ssd_reduce_bounding_boxes: %d priors need %zu bytes of LDS (> 160 KB)", P, lds);
+  if (int rc = set_lds(k_ssd_reduce, lds)) return rc;
+  hipLaunchKernelGGL(k_ssd_reduce, dim3(B), dim3(256), lds, (hipStream_t)stream, x, sc, with_priors, prob_threshold,
+                     iou_threshold, img_w, img_h, out, out_counts);
+  return check_launch("fdet_ssd_reduce_bounding_boxes");
 }
 
 extern "C" int fdet_version(void) { return FDET_VERSION; }

@@ -8,6 +8,34 @@ from .. import hotpath as hp
 from ..hotpath import nms  # noqa: F401  (keyword-compatible stand-in for torchvision.ops.nms)
 
 
+class ReduceSSDBoundingBoxes(nn.Module):
+    """datasets/utils.py:8-92: SSD decode (optionally with priors) -> threshold -> round -> NMS -> xywh."""
+
+    def __init__(self, probability_threshold: float = 0.9, iou_threshold: float = 0.5, input_shape=(3, 320, 240),
+                 patch_sizes=(60, 30, 15, 7), priors=None, with_priors=False):
+        super().__init__()
+        if priors is not None:
+            raise NotImplementedError("custom priors are not supported: the kernel derives them from patch_sizes")
+        self.probability_threshold = probability_threshold
+        self.iou_threshold = iou_threshold
+        self.input_shape = input_shape
+        _, self.width, self.height = input_shape
+        self.patch_sizes = tuple(patch_sizes)
+        self.with_priors = with_priors
+
+    def forward_batch(self, x: torch.Tensor):
+        """(B,P,5) -> (rows (B,P,5) [score,x,y,w,h], counts (B,)), on the GPU, no host sync."""
+        return hp.ssd_reduce_bounding_boxes(x, self.probability_threshold, self.iou_threshold, self.width, self.height,
+                                            self.patch_sizes, self.with_priors)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        rows, counts = self.forward_batch(x.unsqueeze(0))
+        k = int(counts[0])
+        if k == 0:
+            return torch.empty(0).reshape(0, 5)
+        return rows[0, :k]
+
+
 class ReduceBoundingBoxes(nn.Module):
     def __init__(self, probability_threshold: float = 0.9, iou_threshold: float = 0.5,
                  input_shape=(3, 320, 240), num_of_patches=40):

@@ -91,8 +91,8 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torc
     K = boxes.shape[0]
     if K == 0:
         return torch.empty(0, dtype=torch.int64, device=boxes.device)
-    if K > 4096:
-        raise N.FdetError(f"nms: K={K} > 4096 candidates per image is not supported by fdet_nms")
+    if K > 4864:
+        raise N.FdetError(f"nms: K={K} > 4864 candidates per image is not supported by fdet_nms")
     cnt = torch.tensor([K], dtype=I32, device=boxes.device)
     keep, kc = nms_batched(boxes.reshape(1, K, 4), scores.reshape(1, K), cnt, iou_threshold)
     return keep[0, : int(kc[0])].to(torch.int64)
@@ -123,6 +123,77 @@ def step_metrics(gt: torch.Tensor, gt_counts: torch.Tensor, pred: torch.Tensor, 
                                   ptr(pred_counts.to(I32).contiguous(), I32), B, K, ptr(per), ptr(tot), stream()),
           "fdet_step_metrics")
     return per, tot
+
+
+# ------------------------------------------------------------------------------------------
+# SSD detection math (datasets/WIDERFace/dataset_ssd.py, losses/SSDLoss.py, datasets/utils.py:8-92)
+# ------------------------------------------------------------------------------------------
+SSD_PATCH_SIZES = (60, 30, 15, 7)
+
+
+def _ps_array(patch_sizes):
+    import ctypes
+    ps = [int(p) for p in patch_sizes]
+    return (ctypes.c_int * len(ps))(*ps), len(ps)
+
+
+def ssd_num_priors(patch_sizes=SSD_PATCH_SIZES) -> int:
+    arr, n = _ps_array(patch_sizes)
+    P = int(lib().fdet_ssd_num_priors(arr, n))
+    if P < 0:
+        raise N.FdetError("ssd_num_priors: bad patch sizes")
+    return P
+
+
+def ssd_encode_targets(boxes: Sequence[torch.Tensor], img_size: Tuple[int, int], patch_sizes=SSD_PATCH_SIZES,
+                       device=None) -> torch.Tensor:
+    """Batched multi-scale SSD target encode: list of (n_i,5) [conf,x,y,w,h] -> (B,P,5) on the GPU."""
+    B = len(boxes)
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    counts = [int(b.shape[0]) if b.numel() else 0 for b in boxes]
+    offs = torch.zeros(B + 1, dtype=I32)
+    offs[1:] = torch.cumsum(torch.tensor(counts, dtype=torch.int64), 0).to(I32)
+    rows = [b.reshape(-1, 5).to(F32).cpu() for b in boxes if b.numel()]
+    flat = (torch.cat(rows, 0) if rows else torch.zeros(1, 5)).contiguous().to(device)
+    arr, ns = _ps_array(patch_sizes)
+    out = torch.empty(B, ssd_num_priors(patch_sizes), 5, dtype=F32, device=device)
+    if B:
+        check(lib().fdet_ssd_encode_targets(ptr(flat), ptr(offs.to(device), I32), B, arr, ns, float(img_size[0]),
+                                            float(img_size[1]), ptr(out), stream()), "fdet_ssd_encode_targets")
+    return out
+
+
+def ssd_loss_fwd_bwd(pred: torch.Tensor, target: torch.Tensor, neg_pos_ratio: int = 10, want_grad: bool = True,
+                     want_mask: bool = False):
+    """ssd_loss(pred[:,:,0], pred[:,:,1:], target[:,:,0], target[:,:,1:], ratio): (loss (1,), grad or None, mask or None)."""
+    pred, target = _f32(pred), _f32(target)
+    if pred.dim() != 3 or pred.shape[2] != 5 or pred.shape != target.shape:
+        raise ValueError(f"ssd_loss: expected matching (B,P,5) tensors, got {tuple(pred.shape)} / {tuple(target.shape)}")
+    B, P, _ = pred.shape
+    loss = torch.empty(1, dtype=F32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    mask = torch.empty(B, P, dtype=torch.uint8, device=pred.device) if want_mask else None
+    ws = torch.empty(int(lib().fdet_ssd_loss_ws_bytes(B)) // 8 + 1, dtype=torch.float64, device=pred.device)
+    check(lib().fdet_ssd_loss_fwd_bwd(ptr(pred), ptr(target), B, P, int(neg_pos_ratio), ptr(loss), ptr(grad),
+                                      ptr(mask, torch.uint8), ptr(ws, torch.float64), ws.numel() * 8, stream()),
+          "fdet_ssd_loss_fwd_bwd")
+    return loss, grad, mask
+
+
+def ssd_reduce_bounding_boxes(x: torch.Tensor, prob_threshold: float, iou_threshold: float, img_w: float, img_h: float,
+                              patch_sizes=SSD_PATCH_SIZES, with_priors: bool = True):
+    """Batched ReduceSSDBoundingBoxes.forward: (B,P,5) -> (rows (B,P,5), counts (B,))."""
+    x = _f32(x)
+    B, P, five = x.shape
+    if five != 5 or P != ssd_num_priors(patch_sizes):
+        raise ValueError(f"ssd_reduce_bounding_boxes: expected (B,{ssd_num_priors(patch_sizes)},5), got {tuple(x.shape)}")
+    arr, ns = _ps_array(patch_sizes)
+    out = torch.zeros(B, P, 5, dtype=F32, device=x.device)
+    counts = torch.zeros(B, dtype=I32, device=x.device)
+    check(lib().fdet_ssd_reduce_bounding_boxes(ptr(x), B, arr, ns, int(bool(with_priors)), float(prob_threshold),
+                                               float(iou_threshold), float(img_w), float(img_h), ptr(out),
+                                               ptr(counts, I32), stream()), "fdet_ssd_reduce_bounding_boxes")
+    return out, counts
 
 
 def u8_to_f32_norm(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -1,0 +1,73 @@
+"""GPU parity of the SSD detection math (fdet_ssd_*) against the reference-generated fixtures
+(tests/golden/g9_ssd.npz) and the oracle: encode and decode bit-exact, mining mask exact, loss and
+gradients within 1e-5; a 64-image batch against the oracle per image."""
+import pytest
+import torch
+
+import oracle as O
+from oracle import ssd_oracle as S
+
+pytestmark = pytest.mark.gpu
+SIZE = 480
+
+
+@pytest.fixture(scope="module")
+def hp():
+    import fdet_amd
+    from fdet_amd import hotpath
+    return hotpath
+
+
+def test_ssd_encode_matches_reference(hp, golden):
+    g = golden("g9_ssd")
+    lists = [g[f"enc_boxes_{k}"] for k in range(g["enc"].shape[0])]
+    out = hp.ssd_encode_targets(lists, (SIZE, SIZE)).cpu()
+    assert torch.equal(out, g["enc"])
+
+
+def test_ssd_loss_matches_reference(hp, golden):
+    g = golden("g9_ssd")
+    pred, y = g["loss_pred"].cuda(), g["loss_y"].cuda()
+    loss, grad, mask = hp.ssd_loss_fwd_bwd(pred, y, 10, want_grad=True, want_mask=True)
+    assert torch.equal(mask.cpu(), g["mask"])
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert torch.allclose(grad[:, :, 0].cpu(), g["loss_gc"], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(grad[:, :, 1:].cpu(), g["loss_gl"], rtol=1e-5, atol=1e-9)
+    # the mirror of losses/SSDLoss.py with autograd
+    from fdet_amd.losses.SSDLoss import ssd_loss
+    p = pred.clone().requires_grad_(True)
+    l = ssd_loss(p[:, :, 0], p[:, :, 1:], y[:, :, 0], y[:, :, 1:], 10)
+    l.backward()
+    assert torch.allclose(p.grad.cpu()[:, :, 0], g["loss_gc"], rtol=1e-5, atol=1e-9)
+
+
+def test_ssd_reduce_matches_reference(hp, golden):
+    g = golden("g9_ssd")
+    rows, counts = hp.ssd_reduce_bounding_boxes(g["dec_in"].cuda(), 0.5, 0.5, SIZE, SIZE)
+    for n in range(g["dec_in"].shape[0]):
+        k = int(g["dec_counts"][n])
+        assert int(counts[n]) == k
+        assert torch.equal(rows[n, :k].cpu(), g["dec_out"][n, :k])
+
+
+def test_ssd_batch_vs_oracle(hp):
+    """64 images: encode -> loss on random predictions -> reducer, every image against the oracle."""
+    B = 64
+    gen = torch.Generator().manual_seed(77)
+    boxes = O.synthetic_boxes(B, SIZE, seed=13, max_faces=6)
+    enc = hp.ssd_encode_targets(boxes, (SIZE, SIZE))
+    for i in range(0, B, 7):
+        assert torch.equal(enc[i].cpu(), S.ssd_encode(boxes[i] if boxes[i].numel() else torch.tensor([]), (SIZE, SIZE)))
+    P = enc.shape[1]
+    pred = torch.rand(B, P, 5, generator=gen) * 0.98 + 0.01
+    loss, grad, _ = hp.ssd_loss_fwd_bwd(pred.cuda(), enc, 10)
+    ref, gc, gl = S.ssd_loss_and_grads(pred[:, :, 0], pred[:, :, 1:], enc[:, :, 0].cpu(), enc[:, :, 1:].cpu(), 10)
+    assert abs(float(loss) - float(ref)) <= 1e-4 * abs(float(ref))
+    assert torch.allclose(grad[:, :, 0].cpu(), gc, rtol=1e-4, atol=1e-9)
+    assert torch.allclose(grad[:, :, 1:].cpu(), gl, rtol=1e-4, atol=1e-9)
+    x = torch.rand(B, P, 5, generator=gen) * torch.tensor([0.505, 1, 1, 0.3, 0.3])
+    rows, counts = hp.ssd_reduce_bounding_boxes(x.cuda(), 0.5, 0.3, SIZE, SIZE)
+    for i in range(0, B, 9):
+        want = S.reduce_ssd_bounding_boxes(x[i], 0.5, 0.3, (3, SIZE, SIZE))
+        assert int(counts[i]) == want.shape[0]
+        assert torch.equal(rows[i, : want.shape[0]].cpu(), want)
