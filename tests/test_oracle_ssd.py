@@ -43,3 +43,24 @@ def test_ssd_decode_and_reduce(golden):
         k = int(g["dec_counts"][n])
         assert out.shape[0] == k
         assert torch.equal(out, g["dec_out"][n, :k])
+
+
+def test_ssd_model_oracle_matches_reference_class(golden):
+    """oracle/ssd_model_oracle.py against the reference's SSD class (filters 16, 2 images, eval mode):
+    forward output, ssd_loss and the gradient of every parameter (sum / abs-sum, small tensors in full).
+    The parameters are regenerated from the seed (the generator asserted that this reproduces the
+    reference's default init bit for bit)."""
+    from oracle import ssd_model_oracle as SM
+    g = golden("g10_ssd_model")
+    fil, seed = int(g["m_filters"]), int(g["m_seed"])
+    P = SM.init_params(fil, seed)
+    x = torch.rand(2, 3, SIZE, SIZE, generator=torch.Generator().manual_seed(int(g["m_x_seed"])))
+    loss, y, G = SM.loss_and_grads(fil, P, x, g["m_target"])
+    assert torch.allclose(y, g["m_y"], rtol=1e-5, atol=1e-6)
+    assert abs(float(loss) - float(g["m_loss"])) <= 1e-5 * abs(float(g["m_loss"]))
+    for n, gr in G.items():
+        ga = float(g["m_gabs/" + n])
+        assert abs(float(gr.double().abs().sum()) - ga) <= 1e-4 * max(ga, 1e-6), n
+        assert abs(float(gr.double().sum()) - float(g["m_gsum/" + n])) <= 1e-4 * max(ga, 1e-6), n
+        if ("m_grad/" + n) in g:
+            assert torch.allclose(gr, g["m_grad/" + n], rtol=1e-4, atol=1e-7 * max(1.0, ga)), n

@@ -72,3 +72,39 @@ for i, f in enumerate(full):
     pad[i, : f.shape[0]] = f
 out["dec_out"] = pad
 MG.save("g9_ssd", **out)
+
+# ----------------------------------------------------------------------------- SSD model (models/SSD.py)
+import types  # noqa: E402
+import oracle as O  # noqa: E402
+from oracle import ssd_model_oracle as SM  # noqa: E402
+ptf = types.ModuleType("ptflops"); ptf.get_model_complexity_info = lambda *a, **k: ("", "")
+sys.modules["ptflops"] = ptf
+bsm = MG._load_by_path("models.BaseSSDModel", os.path.join(REF, "models", "BaseSSDModel.py"))
+sys.modules["models"].BaseSSDModel = bsm
+ssdmod = MG._load_by_path("models.SSD", os.path.join(REF, "models", "SSD.py"))
+FIL, SEED = 16, 5
+torch.manual_seed(SEED)
+ref_model = ssdmod.SSD(filters=FIL, input_shape=(3, size, size)).eval()
+sd = {k: v for k, v in ref_model.state_dict().items()}
+Pm = SM.init_params(FIL, SEED)
+assert set(Pm) == set(sd), (sorted(set(Pm) ^ set(sd)))
+for k in sd:
+    assert torch.equal(Pm[k], sd[k]), k                                # the seed reproduces the reference's init
+gx = torch.Generator().manual_seed(9)
+xm = torch.rand(2, 3, size, size, generator=gx)
+with torch.no_grad():
+    ym = ref_model(xm)
+tgt = torch.stack([enc[2], enc[3]])
+for p_ in ref_model.parameters():
+    p_.requires_grad_(True)
+yg = ref_model(xm)
+lm = ssdloss.ssd_loss(yg[:, :, 0], yg[:, :, 1:], tgt[:, :, 0], tgt[:, :, 1:], 10)
+lm.backward()
+gout = {"m_x_seed": torch.tensor(9), "m_seed": torch.tensor(SEED), "m_filters": torch.tensor(FIL), "m_y": ym, "m_target": tgt,
+        "m_loss": lm.detach()}
+for n_, p_ in ref_model.named_parameters():
+    gout["m_gsum/" + n_] = p_.grad.double().sum().float()
+    gout["m_gabs/" + n_] = p_.grad.double().abs().sum().float()
+    if p_.grad.numel() <= 4096:
+        gout["m_grad/" + n_] = p_.grad.clone()
+MG.save("g10_ssd_model", **gout)
