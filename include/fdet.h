@@ -143,6 +143,13 @@ int fdet_ssd_reduce_bounding_boxes(const float* x, int B, const int* h_patch_siz
                                    float prob_threshold, double iou_threshold, float img_w, float img_h,
                                    float* out, int32_t* out_counts, void* stream);
 
+/* SSD heads (models/SSD.py:233-245,206-218): z [N,CP,ps,ps] holds Linear(C,5) of one scale in channels 0..4
+ * (CP >= 5, extra channels ignored / zeroed); rows prior_start + i*ps + j of y [N,P,5] get
+ * [sigmoid(z0), z1/ps + i/ps, z2/ps + j/ps, z3, z4].  _bwd maps d loss/d y back to dz (needs y for the sigmoid). */
+int fdet_ssd_head_pack_fwd(const float* z, int N, int CP, int ps, int prior_start, int P, float* y, void* stream);
+int fdet_ssd_head_pack_bwd(const float* dy, const float* y, int N, int CP, int ps, int prior_start, int P, float* dz,
+                           void* stream);
+
 /* Bilinear Resize fused with the /255 normalisation: replaces `self.resize(x) / 255.0`
  * (models/PoolResnet.py:91,95; models/Resnet.py likewise) and `Resize(...)(x); x / 255.0`
  * (models/BaseModel.py:64-65), i.e. torchvision 0.11.2 transforms.Resize on tensors =
@@ -251,7 +258,7 @@ int fdet_block_chain_bwd_bf16x3(const float* dout, const void* const* h_wpk1b, c
 
 /* Residual-block tail for pooled blocks: out = maxpool_pool(c*drop_scale[n,f] + x)
  * (Dropout2d + skip add + MaxPool2d(2), models/PoolResnet.py:39-42).  pool in {1,2}.
- *   c,x [N,F,H,W]; drop_scale [N,F] or NULL; out [N,F,H/pool,W/pool]. */
+ *   c,x [N,F,H,W]; drop_scale [N,F] or NULL; out [N,F,H/pool,W/pool] (floor: an odd last row/column is dropped). */
 int fdet_block_tail_fwd(const float* c, const float* x, const float* drop_scale, float* out,
                         int N, int F, int H, int W, int pool, void* stream);
 

@@ -726,5 +726,56 @@ extern "C" int fdet_ssd_reduce_bounding_boxes(const float* x, int B, const int* 
   return check_launch("fdet_ssd_reduce_bounding_boxes");
 }
 
+// SSD heads: z [N,CP,ps,ps] (channels 0..4 = Linear(C,5) on the NHWC map, models/SSD.py:233-238) ->
+// rows prior_start + i*ps + j of y [N,P,5]: sigmoid on the score (:240), apply_priors (:206-218).
+__global__ void __launch_bounds__(256)
+k_ssd_head_pack_fwd(const float* __restrict__ z, int N, int CP, int ps, int prior_start, int P, float* __restrict__ y) {
+  const int cells = ps * ps;
+  const float mult = (float)(1.0 / ps);
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < N * cells; t += gridDim.x * 256) {
+    const int n = t / cells, c = t - n * cells;
+    const int i = c / ps, j = c - i * ps;
+    const float* zp = z + (size_t)n * CP * cells + c;
+    float* o = y + ((size_t)n * P + prior_start + c) * 5;
+    o[0] = 1.f / (1.f + expf(-zp[0]));
+    o[1] = zp[cells] * mult + (float)i * mult;
+    o[2] = zp[2 * cells] * mult + (float)j * mult;
+    o[3] = zp[3 * cells];
+    o[4] = zp[4 * cells];
+  }
+}
+__global__ void __launch_bounds__(256)
+k_ssd_head_pack_bwd(const float* __restrict__ dy, const float* __restrict__ y, int N, int CP, int ps, int prior_start,
+                    int P, float* __restrict__ dz) {
+  const int cells = ps * ps;
+  const float mult = (float)(1.0 / ps);
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < N * cells; t += gridDim.x * 256) {
+    const int n = t / cells, c = t - n * cells;
+    const float* g = dy + ((size_t)n * P + prior_start + c) * 5;
+    const float s = y[((size_t)n * P + prior_start + c) * 5];
+    float* d = dz + (size_t)n * CP * cells + c;
+    d[0] = g[0] * (s * (1.f - s));
+    d[cells] = g[1] * mult;
+    d[2 * cells] = g[2] * mult;
+    d[3 * cells] = g[3];
+    d[4 * cells] = g[4];
+    for (int k = 5; k < CP; ++k) d[(size_t)k * cells] = 0.f;
+  }
+}
+
+extern "C" int fdet_ssd_head_pack_fwd(const float* z, int N, int CP, int ps, int prior_start, int P, float* y, void* stream) {
+  FDET_REQUIRE(z && y && N > 0 && CP >= 5 && ps > 0 && prior_start >= 0 && prior_start + ps * ps <= P, "ssd_head_pack_fwd: bad arguments");
+  const int total = N * ps * ps;
+  hipLaunchKernelGGL(k_ssd_head_pack_fwd, dim3(min((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, z, N, CP, ps, prior_start, P, y);
+  return check_launch("fdet_ssd_head_pack_fwd");
+}
+extern "C" int fdet_ssd_head_pack_bwd(const float* dy, const float* y, int N, int CP, int ps, int prior_start, int P, float* dz,
+                                      void* stream) {
+  FDET_REQUIRE(dy && y && dz && N > 0 && CP >= 5 && ps > 0 && prior_start >= 0 && prior_start + ps * ps <= P, "ssd_head_pack_bwd: bad arguments");
+  const int total = N * ps * ps;
+  hipLaunchKernelGGL(k_ssd_head_pack_bwd, dim3(min((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, dy, y, N, CP, ps, prior_start, P, dz);
+  return check_launch("fdet_ssd_head_pack_bwd");
+}
+
 extern "C" int fdet_version(void) { return FDET_VERSION; }
 extern "C" const char* fdet_last_error(void) { return fdet::err_buf(); }

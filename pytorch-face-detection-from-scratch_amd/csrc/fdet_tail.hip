@@ -12,7 +12,8 @@ __device__ __forceinline__ void upd(float v, int k, float& m, int& arg) {
   if (v > m || v != v) { m = v; arg = k; }
 }
 
-// pool == 2: one thread per pooled output (H, W even); pool == 1: one thread per element
+// pool == 2: one thread per pooled output (floor(H/2) x floor(W/2): an odd last row / column belongs to
+// no window, as nn.MaxPool2d(2)); pool == 1: one thread per element
 __global__ void __launch_bounds__(256)
 k_tail_fwd(const float* __restrict__ c, const float* __restrict__ x, const float* __restrict__ scale,
            float* __restrict__ out, int NF, int H, int W, int pool) {
@@ -76,7 +77,7 @@ k_tail_bwd(const float* __restrict__ dout, const float* __restrict__ c, const fl
 extern "C" int fdet_block_tail_fwd(const float* c, const float* x, const float* drop_scale, float* out, int N,
                                    int F, int H, int W, int pool, void* stream) {
   FDET_REQUIRE(c && x && out && N > 0 && F > 0 && H > 0 && W > 0, "block_tail_fwd: bad arguments");
-  FDET_REQUIRE(pool == 1 || (pool == 2 && H % 2 == 0 && W % 2 == 0), "block_tail_fwd: pool=%d needs even H,W (H=%d W=%d)", pool, H, W);
+  FDET_REQUIRE(pool == 1 || (pool == 2 && H >= 2 && W >= 2), "block_tail_fwd: pool=%d needs H,W >= 2 (H=%d W=%d)", pool, H, W);
   const size_t total = (size_t)N * F * (H / pool) * (W / pool);
   size_t blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(k_tail_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c, x, drop_scale, out,
@@ -88,8 +89,12 @@ extern "C" int fdet_block_tail_bwd(const float* dout, const float* c, const floa
                                    float* dz2, float* de, int N, int F, int H, int W, int pool, float slope,
                                    void* stream) {
   FDET_REQUIRE(dout && c && dz2 && N > 0 && F > 0 && H > 0 && W > 0, "block_tail_bwd: bad arguments");
-  FDET_REQUIRE(pool == 1 || (pool == 2 && H % 2 == 0 && W % 2 == 0 && x && de),
-               "block_tail_bwd: pool=%d needs even H,W and x,de buffers", pool);
+  FDET_REQUIRE(pool == 1 || (pool == 2 && H >= 2 && W >= 2 && x && de),
+               "block_tail_bwd: pool=%d needs H,W >= 2 and x,de buffers", pool);
+  if (pool == 2 && ((H | W) & 1)) {      // odd map: the last row / column is in no window -> zero gradient
+    (void)hipMemsetAsync(dz2, 0, (size_t)N * F * H * W * sizeof(float), (hipStream_t)stream);
+    (void)hipMemsetAsync(de, 0, (size_t)N * F * H * W * sizeof(float), (hipStream_t)stream);
+  }
   const size_t total = (size_t)N * F * (H / pool) * (W / pool);
   size_t blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(k_tail_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, c, x, drop_scale,

@@ -196,6 +196,20 @@ def ssd_reduce_bounding_boxes(x: torch.Tensor, prob_threshold: float, iou_thresh
     return out, counts
 
 
+def ssd_head_pack_fwd(z: torch.Tensor, ps: int, prior_start: int, y: torch.Tensor) -> None:
+    Nn, CP, H, W = z.shape
+    if H != ps or W != ps or y.dim() != 3 or y.shape[0] != Nn or y.shape[2] != 5:
+        raise ValueError("ssd_head_pack_fwd: shape mismatch")
+    check(lib().fdet_ssd_head_pack_fwd(ptr(z), Nn, CP, ps, int(prior_start), y.shape[1], ptr(y), stream()), "fdet_ssd_head_pack_fwd")
+
+
+def ssd_head_pack_bwd(dy: torch.Tensor, y: torch.Tensor, ps: int, prior_start: int, dz: torch.Tensor) -> None:
+    Nn, CP, H, W = dz.shape
+    if H != ps or W != ps or dy.shape != y.shape or y.shape[0] != Nn or y.shape[2] != 5:
+        raise ValueError("ssd_head_pack_bwd: shape mismatch")
+    check(lib().fdet_ssd_head_pack_bwd(ptr(dy), ptr(y), Nn, CP, ps, int(prior_start), y.shape[1], ptr(dz), stream()), "fdet_ssd_head_pack_bwd")
+
+
 def u8_to_f32_norm(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     if x.dtype != torch.uint8:
         raise TypeError("u8_to_f32_norm expects uint8")

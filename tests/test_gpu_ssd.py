@@ -71,3 +71,40 @@ def test_ssd_batch_vs_oracle(hp):
         want = S.reduce_ssd_bounding_boxes(x[i], 0.5, 0.3, (3, SIZE, SIZE))
         assert int(counts[i]) == want.shape[0]
         assert torch.equal(rows[i, : want.shape[0]].cpu(), want)
+
+
+def test_ssd_model_forward_backward_vs_oracle(golden):
+    """fdet_amd.models.SSD.SSD (filters 16) on the GPU: eval forward against the reference class's output
+    (fixture), then a training-mode step with injected dropout masks -- output, ssd_loss and the gradient of
+    every parameter against the oracle's autograd (1e-4 of each tensor's scale; bf16x3 convs ~1e-5)."""
+    import fdet_amd
+    from fdet_amd.models.SSD import SSD
+    from fdet_amd.losses.SSDLoss import ssd_loss
+    from oracle import ssd_model_oracle as SM
+    g = golden("g10_ssd_model")
+    fil, seed = int(g["m_filters"]), int(g["m_seed"])
+    P = SM.init_params(fil, seed)
+    model = SSD(filters=fil, input_shape=(3, SIZE, SIZE))
+    model.load_state_dict({k: v.clone() for k, v in P.items()})
+    model = model.cuda().eval()
+    x = torch.rand(2, 3, SIZE, SIZE, generator=torch.Generator().manual_seed(int(g["m_x_seed"])))
+    with torch.no_grad():
+        y = model(x.cuda()).cpu()
+    assert torch.allclose(y, g["m_y"], rtol=1e-4, atol=1e-4)
+    # training step with dropout
+    masks = SM.make_dropout_masks(fil, 2, seed=3)
+    tgt = g["m_target"]
+    loss_ref, y_ref, G_ref = SM.loss_and_grads(fil, P, x, tgt, masks)
+    model.train()
+    model.set_dropout_masks(masks)
+    yt = model(x.cuda())
+    assert torch.allclose(yt.detach().cpu(), y_ref, rtol=1e-4, atol=1e-4)
+    tg = tgt.cuda()
+    loss = ssd_loss(yt[:, :, 0], yt[:, :, 1:], tg[:, :, 0], tg[:, :, 1:], 10)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-4 * max(1.0, abs(float(loss_ref)))
+    loss.backward()
+    for n, p in model.named_parameters():
+        ref = G_ref[n].double()
+        got = p.grad.detach().cpu().double()
+        rel = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert rel <= 5e-3, (n, rel)                    # pool-argmax routing makes single entries jumpy (see test_gpu_model)
