@@ -1,0 +1,84 @@
+"""`ModelMetaSSD` with the reference's surface (models/ModelMetaSSD.py:85-235): forward,
+configure_optimizers, step / training_step / validation_step, plus `fused_train_step` (forward +
+ssd_loss + backward + Adam as direct kernel launches).  Metrics as in step(): per-image
+ReduceSSDBoundingBoxes on targets and predictions, box_iou hits at 0.5 (fdet_step_metrics)."""
+from pathlib import Path
+
+import torch
+
+from .. import hotpath as hp
+from ..losses.SSDLoss import ssd_loss
+from ..optim import SAMSGD
+
+try:                                                     # pragma: no cover - not in this image
+    from pytorch_lightning import LightningModule as _Base
+except Exception:                                        # noqa: BLE001
+    _Base = torch.nn.Module
+
+
+class ModelMetaSSD(_Base):
+    def __init__(self, model, lr=1e-4, pretrained=False, log_path=Path("out.log"), *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.model = model
+        self.lr = lr
+        self.automatic_optimization = True
+        self.log_path = log_path
+        self.opt = None
+        self._logged = {}
+
+    def log(self, name, value, **kwargs):
+        self._logged[name] = value
+
+    def forward(self, x):
+        return self.model(x)
+
+    def configure_optimizers(self):
+        optimizer = SAMSGD(self.parameters(), lr=self.lr)
+        optimizer.on_params_updated = self.model.engine.mark_params_dirty
+        self.opt = optimizer
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[40], gamma=0.1)
+        return [optimizer], [scheduler]
+
+    @torch.no_grad()
+    def _metrics(self, y_hat, y):
+        red = self.model.reduce_bounding_boxes
+        gt, gc = red.forward_batch(y)
+        pr, pc = red.forward_batch(y_hat.detach())
+        _, tot = hp.step_metrics(gt, gc, pr, pc)
+        return tot
+
+    def step(self, batch, batch_idx, validation=False):
+        x, y, gt_bbxs = batch
+        y_hat = self.forward(x)
+        loss = ssd_loss(y_hat[:, :, 0], y_hat[:, :, 1:], y[:, :, 0], y[:, :, 1:], 10)      # :178
+        tot = self._metrics(y_hat, y)
+        out = {"loss": loss, "total_iou": tot[0], "total_recall": tot[1], "total_precision": tot[2]}
+        self.log("step_loss", loss, prog_bar=True, logger=True, on_step=True)
+        return out
+
+    def training_step(self, batch, batch_idx):
+        return self.step(batch, batch_idx)
+
+    def validation_step(self, batch, batch_idx):
+        return self.step(batch, batch_idx, validation=True)
+
+    def test_step(self, batch, batch_idx):
+        return self.step(batch, batch_idx, validation=True)
+
+    def fused_train_step(self, x, y):
+        """One optimisation step on (x (N,3,480,480) in [0,1], y (N,4774,5)); returns (loss (1,), y_hat)."""
+        if self.opt is None:
+            self.configure_optimizers()
+        model, eng = self.model, self.model.engine
+        names, params = model.named_stack_params()
+        sp = self.opt._space()
+        if [id(p) for p in sp.params] != [id(p) for p in params]:
+            raise RuntimeError("optimizer parameter order differs from the SSD stack's")
+        P = {n: p.data for n, p in zip(names, params)}
+        G = {n: sp.view(sp.grad, i) for i, n in enumerate(names)}
+        masks = model._draw_masks(x.shape[0], x.device) if model.training else None
+        y_hat, saved = eng.forward(x, P, masks, save=True)
+        loss, dy, _ = hp.ssd_loss_fwd_bwd(y_hat, y, 10, want_grad=True)
+        eng.backward(saved, dy, P, G)
+        self.opt.step(grads_in_flat=True)
+        return loss, y_hat

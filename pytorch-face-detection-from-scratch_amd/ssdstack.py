@@ -35,13 +35,14 @@ def block_specs(filters: int):
 
 
 def param_names(filters: int) -> List[str]:
+    """state_dict order of the reference module (stem, all blocks, then the Linear heads)."""
     names = ["input_normalizer.weight", "input_normalizer.bias"]
     for name, ci, co, _, head in block_specs(filters):
         if ci != co:
             names += [name + ".pointwise_conv_skip.weight", name + ".pointwise_conv_skip.bias"]
         names += [name + ".conv1.weight", name + ".conv1.bias", name + ".conv2.weight", name + ".conv2.bias"]
-        if head >= 0:
-            names += [f"extracting_layers.{head}.0.weight", f"extracting_layers.{head}.0.bias"]
+    for head in range(len(PATCH_SIZES)):
+        names += [f"extracting_layers.{head}.0.weight", f"extracting_layers.{head}.0.bias"]
     return names
 
 

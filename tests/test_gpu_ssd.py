@@ -108,3 +108,39 @@ def test_ssd_model_forward_backward_vs_oracle(golden):
         got = p.grad.detach().cpu().double()
         rel = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
         assert rel <= 5e-3, (n, rel)                    # pool-argmax routing makes single entries jumpy (see test_gpu_model)
+
+
+def test_ssd_fused_train_step_vs_oracle():
+    """ModelMetaSSD.fused_train_step (forward + ssd_loss + backward + Adam, no autograd) against the oracle:
+    loss within 1e-4, parameters after the step within Adam's first-step scale (lr) with at most a few
+    sign flips of noise-level gradient entries per tensor."""
+    import fdet_amd
+    from fdet_amd import hotpath as hp
+    from fdet_amd.models.SSD import SSD
+    from fdet_amd.models.ModelMetaSSD import ModelMetaSSD
+    from oracle import ssd_model_oracle as SM
+    fil, B = 16, 2
+    P = SM.init_params(fil, seed=11)
+    model = SSD(filters=fil, input_shape=(3, SIZE, SIZE))
+    model.load_state_dict({k: v.clone() for k, v in P.items()})
+    model = model.cuda().train()
+    mm = ModelMetaSSD(model=model, lr=1e-4)
+    mm.configure_optimizers()
+    x = torch.rand(B, 3, SIZE, SIZE, generator=torch.Generator().manual_seed(12))
+    boxes = O.synthetic_boxes(B, SIZE, seed=13, max_faces=5)
+    tgt = torch.stack([S.ssd_encode(b if b.numel() else torch.tensor([]), (SIZE, SIZE)) for b in boxes])
+    masks = SM.make_dropout_masks(fil, B, seed=14)
+    loss_ref, y_ref, G_ref = SM.loss_and_grads(fil, P, x, tgt, masks)
+    names = list(P)
+    state = {"exp_avg": {k: torch.zeros_like(v) for k, v in P.items()}, "exp_avg_sq": {k: torch.zeros_like(v) for k, v in P.items()}}
+    Pn = {k: v.clone() for k, v in P.items()}
+    O.adam_step([Pn[n] for n in names], [G_ref[n] for n in names], [state["exp_avg"][n] for n in names],
+                [state["exp_avg_sq"][n] for n in names], 1, lr=1e-4)
+    model.set_dropout_masks(masks)
+    loss, y_hat = mm.fused_train_step(x.cuda(), tgt.cuda())
+    assert torch.allclose(y_hat.cpu(), y_ref, rtol=1e-4, atol=1e-4)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-4 * max(1.0, abs(float(loss_ref)))
+    for n, p in model.named_parameters():
+        d = (p.detach().cpu() - Pn[n]).abs()
+        assert float(d.max()) <= 2.1e-4, n
+        assert int((d > 2e-6).sum()) <= max(3, int(0.03 * d.numel())), n
