@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--filters", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true", help="skip the inference leg (profiling runs: its launches share kernel symbols with training)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,17 +170,19 @@ def main():
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         # ---- roofline of the dominant kernel (live HIP-event timing over the timed region, on the
-        # stream the kernels are launched on).  The 3x3 conv forward / data-gradient share ONE kernel
-        # symbol (k_conv3x3_x3_sb<2,2> in bf16x3 arithmetic at 60x60 and 30x30, k_conv3x3 in fp32):
-        # every launch of that symbol is pooled, so avg_launch_ms is the average rocprofv3 --stats
-        # reports for it.  bf16x3 convs are HBM-bound (peak 8 TB/s); the exact-fp32 path is bound by
-        # the fp32 MFMA rate (157.3 TFLOP/s).
+        # stream the kernels are launched on).  Each (kind, resolution) group is one kernel symbol in
+        # this model (e.g. conv3x3_wgrad@60x60 = k_wgrad3x3_x3<2,4,false,false>, one launch per step
+        # for both 60x60 layers; conv3x3_fwd@60x60 = k_conv3x3_x3_sb<2,2,4,FWD_FULL>), so
+        # avg_launch_ms is the average `rocprofv3 --stats` reports for that symbol when the same
+        # command is profiled with --no-inference (the inference leg reuses the forward symbols).
+        # bf16x3 convs are HBM-bound (peak 8 TB/s); the exact-fp32 path is bound by the fp32 MFMA
+        # rate (157.3 TFLOP/s).
         per = timer.summary()                                # name -> (launches, total ms, flops/launch, bytes/launch)
         x3 = bool(model.engine.x3)
         groups = {}
         for k, (n_l, tot, fl, nb) in per.items():
             kind, shape = k.split("@")
-            g = "conv3x3_fwd+dgrad" if kind in ("conv3x3_fwd", "conv3x3_dgrad") else k
+            g = k                                            # one kernel symbol per (kind, resolution) in this model
             a = groups.setdefault(g, [0, 0.0, 0.0, 0.0])
             a[0] += n_l; a[1] += tot; a[2] += fl * n_l; a[3] += nb * n_l
         dom = max(groups, key=lambda k: groups[k][1])
@@ -215,7 +218,7 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": roof, "kernel_ms_per_step": breakdown, "final_loss": round(loss_val, 4),
         }
-        if world == 1:
+        if world == 1 and not args.no_inference:
             out["inference"] = infer_bench(model, size, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F_, size, S, sample_bs=64, steps=24)
