@@ -123,15 +123,23 @@ k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* _
       D[fl * DS + ox] = (ff < F) ? dy[(((size_t)n * F + ff) * Ho + oy) * Wo + ox] : 0.f;
     }
     __syncthreads();
+    // tap offsets are wave-uniform and row-invariant: keep the divisions out of the ox loop
+    int xoff[KPW];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+      const int k = min(wid * KPW + j, G::KK - 1);
+      const int ci = k / (KS * KS), r = k - ci * (KS * KS);
+      const int ky = r / KS, kx = r - ky * KS;
+      xoff[j] = (ci * KS + ky) * XS + kx;
+    }
+    const float* Dl = D + lane * DS;
+#pragma unroll 4
     for (int ox = 0; ox < Wo; ++ox) {
-      const float dv = D[lane * DS + ox];
+      const float dv = Dl[ox];
       if (wid == 0) bsum += dv;
 #pragma unroll
       for (int j = 0; j < KPW; ++j) {
-        const int k = wid * KPW + j;                  // wave-uniform
-        const int ci = k / (KS * KS), r = k - ci * (KS * KS);
-        const int ky = r / KS, kx = r - ky * KS;
-        const float xv = (k < G::KK) ? X[(ci * KS + ky) * XS + ox * ST + kx] : 0.f;
+        const float xv = (wid * KPW + j < G::KK) ? X[xoff[j] + ox * ST] : 0.f;
         acc[j] = fmaf(dv, xv, acc[j]);
       }
     }
