@@ -343,6 +343,347 @@ k_wgrad3x3_x3(const WgX3Args a) {
   }
 }
 
+// hi/lo split of two floats with packed ops: 5 VALU per pair (cvt_pk, shift, mask, pk_add with negated
+// operand, cvt_pk); hi and lo come back as bf16 pairs in one dword each.  Same values as put_split (RNE).
+__device__ __forceinline__ void split_pair(float f0, float f1, unsigned& hi, unsigned& lo) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t h = {(__bf16)f0, (__bf16)f1};
+  hi = __builtin_bit_cast(unsigned, h);
+  const f32x2 hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+  const f32x2 l = f32x2{f0, f1} - hf;
+  const bf16x2_t lb = {(__bf16)l[0], (__bf16)l[1]};
+  lo = __builtin_bit_cast(unsigned, lb);
+}
+template <int VW, int DBG = 0>
+__device__ __forceinline__ void put_split_pk(__bf16* hi, __bf16* lo, const typename Vec<VW>::T& v) {
+  if constexpr (VW == 4) {
+    unsigned h0, l0, h1, l1;
+    if (DBG & 32) { h0 = __builtin_bit_cast(unsigned, v[0]); h1 = __builtin_bit_cast(unsigned, v[1]); l0 = __builtin_bit_cast(unsigned, v[2]); l1 = __builtin_bit_cast(unsigned, v[3]); }
+    else { split_pair(v[0], v[1], h0, l0); split_pair(v[2], v[3], h1, l1); }
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    if (DBG & 16) { asm volatile("" ::"v"(h0), "v"(h1), "v"(l0), "v"(l1)); return; }
+    *reinterpret_cast<u32x2_t*>(hi) = u32x2_t{h0, h1};
+    *reinterpret_cast<u32x2_t*>(lo) = u32x2_t{l0, l1};
+  } else if constexpr (VW == 2) {
+    unsigned h0, l0;
+    split_pair(v[0], v[1], h0, l0);
+    *reinterpret_cast<unsigned*>(hi) = h0;
+    *reinterpret_cast<unsigned*>(lo) = l0;
+  } else {
+    put_split<1>(hi, lo, 0, v);
+  }
+}
+
+// Staging loads of the pipelined kernel: buffer loads issued from asm, so that (a) the destination
+// class is ours -- one of the two in-flight register sets lives in the 112 accumulation registers the
+// nine accumulator tiles leave free, the other in arch VGPRs -- and (b) the waits are ours: hipcc
+// merged its own counted waits to vmcnt(0) at the loop head (and, out of VGPRs, parked loaded values
+// in AGPRs with a copy right behind the load), which serialised memory and matrix phases.  An offset
+// past the descriptor's range returns zeros: the predicate of a padded / out-of-batch element is folded
+// into the offset, no branch.  Protocol (cdna_hip_programming.md 5.7 form ii): loads "=a"/"=v", then
+// one s_waitcnt vmcnt(N) and a "+a"/"+v" pass-through of every destination before the first consumer.
+template <int VW, bool AG>
+__device__ __forceinline__ void aload(typename Vec<VW>::T& d, unsigned off, const u32x4& rs) {
+  if constexpr (VW == 4) {
+    if constexpr (AG) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(d) : "v"(off), "s"(rs));
+    else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d) : "v"(off), "s"(rs));
+  } else if constexpr (VW == 2) {
+    if constexpr (AG) asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=a"(d) : "v"(off), "s"(rs));
+    else asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(d) : "v"(off), "s"(rs));
+  } else {
+    if constexpr (AG) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=a"(d) : "v"(off), "s"(rs));
+    else asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(d) : "v"(off), "s"(rs));
+  }
+}
+template <bool AG, class T>
+__device__ __forceinline__ void apass(T& d) {
+  if constexpr (AG) asm volatile("" : "+a"(d)); else asm volatile("" : "+v"(d));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined variant (64 output channels per workgroup; rows of four floats or one float per lane, P = 16 VW):
+// bands of R * P = 128 positions (nine 16-position MFMA steps), TWO LDS tiles, contiguous bands per workgroup.
+// While the MFMAs of band b run on tile b & 1,
+//   * the split + LDS writes ("jobs") of band b+1, whose fp32 rows are already in registers, ride one per
+//     tap group (three MFMAs) behind sched_barriers, so their VALU issues in the MFMAs' shadow;
+//   * the global loads of band b+3 follow four slots behind the job that freed their register: two register
+//     sets in flight (one in the accumulation registers the nine accumulators leave free, one in arch VGPRs),
+//     waited for with a counted vmcnt one whole band later;
+//   * the two x halo rows a band shares with its predecessor are copied LDS -> LDS from the other tile
+//     (no global re-read, no split).
+// The staging phase of the single-tile kernel (matrix pipe idle: one wave per SIMD, nothing else to fill it)
+// is gone; what remains additive is measured in the DBG note below.
+// ---------------------------------------------------------------------------------------------
+// DBG (development builds, -DFDET_WG_DBG + env FDET_WG_DBG=<sum of bits>; wrong results, timing only): 1 no staging
+// jobs, 2 no global loads in the loop, 4 no MFMA steps, 8 every load from image 0 (L2-resident), 16 jobs without
+// their LDS writes, 32 jobs without the split arithmetic, 64 non-zero initial tiles.  Measured with them on the
+// 60x60 layers (ms per launch incl. reduce): MFMA alone on zero tiles 0.350, on non-zero tiles 0.405 (clock),
+// + L2-resident loads +0.00, + split VALU +0.04, + LDS writes +0.04, + real HBM traffic +0.07 -> 0.56.
+template <int VW, int DBG = 0>
+__global__ void __launch_bounds__(NTHR, 1)
+k_wgrad3x3_x3_pipe(const WgX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MTC = 2, MB = 64, ZCH = 4, XCH = 2;
+  constexpr int RZ = 32 / (ZCH * VW);                  // dz rows per band held in registers (= R)
+  constexpr int RX = RZ + 2;
+  using VT = typename Vec<VW>::T;
+  // compile-time tile geometry (plan_x3 computes the same numbers; the launcher checks them)
+  constexpr int P = 16 * VW, R = RZ, KEXT = 144, QZ = KEXT + 24, PX = KEXT + 2 * P + 8;
+  static_assert(R * P == 128 && (QZ / 8) % 2 == 1 && (PX / 8) % 2 == 1, "band = 128 positions, odd 16-byte row pitches");
+  constexpr int tile_elems = MB * QZ * 2 + 32 * PX * 2;          // bf16 elements per tile (hi + lo, Z then X)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int cib = blockIdx.y, cob = blockIdx.z % a.ncob, layer = blockIdx.z / a.ncob;
+  const float* __restrict__ gx = a.x[layer];
+  const float* __restrict__ gdz = a.dz[layer];
+  const int m = wid & 1, kh = wid >> 1;
+  const int H1 = a.H + 1, W = a.W;
+  const int ks0 = kh ? 4 : 0, ks1 = kh ? 9 : 4;                 // nine 16-position steps: 4 + 5
+  __bf16* const base = reinterpret_cast<__bf16*>(smem);
+  {
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    constexpr int n16 = 2 * tile_elems * 2 / 16;
+    for (int t = tid; t < n16; t += NTHR) z[t] = (DBG & 64) ? f32x4{1.37f + t, -0.731f * t, 3.3e-3f * t, 1.1f} : f32x4{0.f, 0.f, 0.f, 0.f};   // pads stay zero
+  }
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  constexpr int p8 = P / 8;
+  const int xv = tid & 15, chl = tid >> 4;
+  const bool lane_ok = xv < W / VW;
+  const int co0 = cob * MB, ci0 = cib * 32;
+  const int HW = a.H * W;
+  float bpart[ZCH];
+#pragma unroll
+  for (int c = 0; c < ZCH; ++c) bpart[c] = 0.f;
+  const unsigned long long pa_z = (unsigned long long)gdz, pa_x = (unsigned long long)gx;
+  const u32x4 rz = {(unsigned)pa_z, (unsigned)(pa_z >> 32), (unsigned)(a.N * a.Cout * HW) * 4u, 0x00020000u};
+  const u32x4 rx = {(unsigned)pa_x, (unsigned)(pa_x >> 32), (unsigned)(a.N * a.Cin * HW) * 4u, 0x00020000u};
+  unsigned zch_off[ZCH], xch_off[XCH];
+  bool zch_ok[ZCH], xch_ok[XCH];
+#pragma unroll
+  for (int c = 0; c < ZCH; ++c) { zch_off[c] = (unsigned)(co0 + c * 16 + chl) * HW * 4u; zch_ok[c] = co0 + c * 16 + chl < a.Cout; }
+#pragma unroll
+  for (int c = 0; c < XCH; ++c) { xch_off[c] = (unsigned)(ci0 + c * 16 + chl) * HW * 4u; xch_ok[c] = ci0 + c * 16 + chl < a.Cin; }
+  // two register sets, used alternately (0: accumulation registers, 1: arch VGPRs): register l of a set is
+  // re-loaded (band + 2) a few slots after job l staged it, so every load has more than one whole band of
+  // MFMAs to land
+  VT pz0[ZCH][RZ], px0[XCH][RX], pz1[ZCH][RZ], px1[XCH][RX];
+  // A workgroup walks CONTIGUOUS bands: the first two x rows of a band are the last two of the band before,
+  // already split in the other tile -- they are copied LDS -> LDS (no global re-read, no VALU), so a band
+  // loads and splits R new rows of dz and R new rows of x.
+  constexpr int NZJ = ZCH * RZ, NXJ = XCH * RZ, NJ = NZJ + NXJ;   // jobs = loads per set
+  constexpr int JPS = (NJ + 27) / 28;                         // jobs (and loads) per slot
+  constexpr int LDS0 = 4;                                     // load l rides LDS0 slots behind job l
+  // load L (0 .. NJ-1) of the band whose first virtual row is V0 into register L of set S
+#define WGP_LOAD1(S, L, V0)                                                                       \
+  {                                                                                               \
+    if ((L) < NZJ) {                                                                              \
+      const int c_ = (L) / RZ, r_ = (L) % RZ;                                                 \
+      const int v = (V0) + r_;                                                                    \
+      const int n = (int)__umulhi((unsigned)min(v, a.VR), a.magic_h1), yy = v - n * H1 - 1;       \
+      const bool ok = v < a.VR && yy >= 0 && lane_ok && zch_ok[c_];                               \
+      const unsigned off = ((unsigned)(((DBG & 8) ? 0 : n) * a.Cout * a.H + yy) * W + xv * VW) * 4u + zch_off[c_];  \
+      aload<VW, S == 0>(pz##S[c_][r_], ok ? off : 0x80000000u, rz);                               \
+    } else {                                                                                      \
+      const int l2_ = (L) - NZJ < NXJ ? (L) - NZJ : 0;                                        \
+      const int c_ = l2_ / RZ, r_ = 2 + l2_ % RZ;                                             \
+      const int v = (V0) - 1 + r_;                                                                \
+      const int n = (int)__umulhi((unsigned)min(max(v, 0), a.VR), a.magic_h1), yy = v - n * H1 - 1; \
+      const bool ok = v >= 0 && v < a.VR && yy >= 0 && lane_ok && xch_ok[c_];                     \
+      const unsigned off = ((unsigned)(((DBG & 8) ? 0 : n) * a.Cin * a.H + yy) * W + xv * VW) * 4u + xch_off[c_];   \
+      aload<VW, S == 0>(px##S[c_][r_], ok ? off : 0x80000000u, rx);                               \
+    }                                                                                             \
+  }
+  // all but the NKEEP youngest loads have landed; every register of set S passes through the wait
+#define WGP_WAIT(S, NKEEP)                                                                        \
+  {                                                                                               \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKEEP));                                             \
+    _Pragma("unroll") for (int c_ = 0; c_ < ZCH; ++c_)                                            \
+      _Pragma("unroll") for (int r_ = 0; r_ < RZ; ++r_) apass<S == 0>(pz##S[c_][r_]);             \
+    _Pragma("unroll") for (int c_ = 0; c_ < XCH; ++c_)                                            \
+      _Pragma("unroll") for (int r_ = 2; r_ < RX; ++r_) apass<S == 0>(px##S[c_][r_]);             \
+  }
+  // staging job J (0 .. NJ-1) of the band in set S into tile TB; branch-free: the 16 lanes of a row cover its
+  // whole pitch (16 * VW = P), lanes past the row's width hold zeros (their loads are out of range) and
+  // write them into the pad columns, which must be zero anyway
+#define WGP_JOB(S, J, TB)                                                                         \
+  {                                                                                               \
+    __bf16* tb_ = base + (TB) * tile_elems;                                                       \
+    if ((J) < NZJ) {                                                                              \
+      const int c_ = (J) / RZ, r_ = (J) % RZ;                                                 \
+      __bf16* zh_ = tb_ + (c_ * 16 + chl) * QZ + ZP + r_ * P + xv * VW;                         \
+      put_split_pk<VW, DBG>(zh_, zh_ + MB * QZ, pz##S[c_][r_]);                                            \
+      _Pragma("unroll") for (int k_ = 0; k_ < VW; ++k_) bpart[c_] += vget<VW>(pz##S[c_][r_], k_); \
+    } else {                                                                                      \
+      const int j2_ = (J) - NZJ < NXJ ? (J) - NZJ : 0;                                        \
+      const int c_ = j2_ / RZ, r_ = 2 + j2_ % RZ;                                                 \
+      __bf16* xh_ = tb_ + 2 * MB * QZ + (c_ * 16 + chl) * PX + XP + r_ * P + xv * VW;         \
+      put_split_pk<VW, DBG>(xh_, xh_ + 32 * PX, px##S[c_][r_]);                                            \
+    }                                                                                             \
+  }
+  // operand fragments of one 16-position MFMA step, two sets (the reads of step s+1 are issued inside step s)
+  bf16x8 fz[2][6], fb[2][6];
+  // halo copy: 64 x rows (32 channels, hi and lo) x 2P elements = VW 16-byte chunks per thread
+  bf16x8 cpy[VW];
+  int cp_off[VW];
+#pragma unroll
+  for (int i = 0; i < VW; ++i) { const int q = tid + NTHR * i; cp_off[i] = 2 * MB * QZ + (q / (4 * VW)) * PX + XP + (q % (4 * VW)) * 8; }
+#define WGP_FRAGS(F, TB, KS_)                                                                     \
+  {                                                                                               \
+    const __bf16* tb_ = base + (TB) * tile_elems;                                                 \
+    const bf16x8* zh_ = reinterpret_cast<const bf16x8*>(tb_ + (m * 32 + l31) * QZ) + half;      \
+    const bf16x8* zl_ = reinterpret_cast<const bf16x8*>(tb_ + MB * QZ + (m * 32 + l31) * QZ) + half; \
+    const bf16x8* xh_ = reinterpret_cast<const bf16x8*>(tb_ + 2 * MB * QZ + l31 * PX) + half;  \
+    const bf16x8* xl_ = reinterpret_cast<const bf16x8*>(tb_ + 2 * MB * QZ + 32 * PX + l31 * PX) + half; \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                            \
+      fz[F][i_] = zh_[2 * (KS_) + i_]; fz[F][3 + i_] = zl_[2 * (KS_) + i_];                       \
+      fb[F][i_] = xh_[2 * (KS_) + i_ * p8]; fb[F][3 + i_] = xl_[2 * (KS_) + i_ * p8];             \
+    }                                                                                             \
+  }
+  // slot U (0 .. 31: eight per MFMA step, behind tap groups 1..8) of a band: its jobs, then its loads
+#define WGP_SLOT(S, U, V0N)                                                                       \
+  {                                                                                               \
+    if ((U) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < VW; ++i_) cpy[i_] = *reinterpret_cast<const bf16x8*>(base + (1 - (S)) * tile_elems + cp_off[i_] + RZ * P); } \
+    if ((U) == 2) { _Pragma("unroll") for (int i_ = 0; i_ < VW; ++i_) *reinterpret_cast<bf16x8*>(base + (S) * tile_elems + cp_off[i_]) = cpy[i_]; } \
+    _Pragma("unroll") for (int q_ = 0; q_ < JPS; ++q_) {                                          \
+      if (!(DBG & 1) && (U) * JPS + q_ < NJ) WGP_JOB(S, ((U) * JPS + q_ < NJ ? (U) * JPS + q_ : 0), S) \
+    }                                                                                             \
+    _Pragma("unroll") for (int q_ = 0; q_ < JPS; ++q_) {                                          \
+      if (!(DBG & 2) && (U) >= LDS0 && ((U) - LDS0) * JPS + q_ < NJ)                              \
+        WGP_LOAD1(S, (((U) - LDS0) * JPS + q_ < NJ && (U) >= LDS0 ? ((U) - LDS0) * JPS + q_ : 0), V0N) \
+    }                                                                                             \
+  }
+  // MFMA step ST (0..3: with slots; 4: the odd step of the second K half) of the band on tile PAR, fragment set F
+#define WGP_STEP(PAR, S, ST, F, V0N)                                                              \
+  {                                                                                               \
+    bf16x8 ah[3], al[3];                                                                          \
+    ah[1] = fz[F][1]; al[1] = fz[F][4];                                                           \
+    ah[0] = shift_chunks<0>(fz[F][1], fz[F][2]); al[0] = shift_chunks<0>(fz[F][4], fz[F][5]);     \
+    ah[2] = shift_chunks<1>(fz[F][0], fz[F][1]); al[2] = shift_chunks<1>(fz[F][3], fz[F][4]);     \
+    _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                              \
+      _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                          \
+        const int t = ky * 3 + kx;                                                                \
+        if (!(DBG & 4)) {                                                                         \
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kx], fb[F][3 + ky], acc[t], 0, 0, 0); \
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kx], fb[F][ky], acc[t], 0, 0, 0);   \
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kx], fb[F][ky], acc[t], 0, 0, 0);   \
+        }                                                                                         \
+        if (t == 1 && (ST) < 3) WGP_FRAGS((F) ^ 1, PAR, ks0 + (ST) + 1)                           \
+        if (t == 1 && (ST) == 3 && ks0 + 4 < ks1) WGP_FRAGS((F) ^ 1, PAR, ks0 + 4)                \
+        if ((ST) < 4 && t >= 1) WGP_SLOT(S, (ST) * 8 + t - 1, V0N)                                \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+      }                                                                                           \
+  }
+  const int bpw = (a.nbands + (int)gridDim.x - 1) / (int)gridDim.x;       // contiguous bands per workgroup
+  int item = blockIdx.x * bpw;
+  const int last = min(item + bpw, a.nbands);
+  const int vnone = a.VR + 8;                            // first row of a band that is not this workgroup's: every row fails v < VR
+  // the first band's x halo rows (virtual rows V0 - 1, V0) come from global memory
+  VT hx[XCH][2];
+  {
+    const bool b0 = item < last;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int v = item * R - 1 + r;
+      const int n = (int)__umulhi((unsigned)min(max(v, 0), a.VR), a.magic_h1), yy = v - n * H1 - 1;
+#pragma unroll
+      for (int c = 0; c < XCH; ++c) {
+        const bool ok = b0 && v >= 0 && v < a.VR && yy >= 0 && lane_ok && xch_ok[c];
+        aload<VW, false>(hx[c][r], ok ? ((unsigned)(n * a.Cin * a.H + yy) * W + xv * VW) * 4u + xch_off[c] : 0x80000000u, rx);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < NJ; ++l) WGP_LOAD1(0, l, (b0 ? item * R : vnone))
+  }
+  WGP_WAIT(0, 0)
+#pragma unroll
+  for (int c = 0; c < XCH; ++c) { apass<false>(hx[c][0]); apass<false>(hx[c][1]); }
+  __syncthreads();                                       // zero fill done
+#pragma unroll
+  for (int c = 0; c < XCH; ++c)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      __bf16* xh_ = base + 2 * MB * QZ + (c * 16 + chl) * PX + XP + r * P + xv * VW;
+      put_split<VW>(xh_, xh_ + 32 * PX, 0, hx[c][r]);
+    }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) WGP_JOB(0, j, 0)
+#pragma unroll
+  for (int l = 0; l < NJ; ++l) WGP_LOAD1(1, l, (item + 1 < last ? (item + 1) * R : vnone))
+#pragma unroll
+  for (int l = 0; l < NJ; ++l) WGP_LOAD1(0, l, (item + 2 < last ? (item + 2) * R : vnone))
+  __syncthreads();
+  // one band on tile PAR; the jobs of the next band (register set S = PAR ^ 1, into tile S) and the loads of
+  // the band three ahead ride on MFMA steps 0..3, which every wave has (nine steps, two K halves).
+  // In flight at the wait: set S (older), then set PAR.  Bands past the workgroup's last load zeros.
+#define WGP_BAND(PAR, S)                                                                          \
+  {                                                                                               \
+    const int v0n_ = item + 3 < last ? (item + 3) * R : vnone;                                    \
+    WGP_FRAGS(0, PAR, ks0)                                                                        \
+    WGP_WAIT(S, NJ)                                                                               \
+    WGP_STEP(PAR, S, 0, 0, v0n_)                                                                  \
+    WGP_STEP(PAR, S, 1, 1, v0n_)                                                                  \
+    WGP_STEP(PAR, S, 2, 0, v0n_)                                                                  \
+    WGP_STEP(PAR, S, 3, 1, v0n_)                                                                  \
+    if (ks0 + 4 < ks1) WGP_STEP(PAR, S, 4, 0, v0n_)                                               \
+    __syncthreads();                                                                              \
+    item += 1;                                                                                    \
+  }
+  while (item < last) {
+    WGP_BAND(0, 1)
+    if (item >= last) break;
+    WGP_BAND(1, 0)
+  }
+  WGP_WAIT(0, 0)                                         // the last bands' (all-zero) loads still target live registers
+  WGP_WAIT(1, 0)
+#undef WGP_BAND
+#undef WGP_STEP
+#undef WGP_SLOT
+#undef WGP_FRAGS
+#undef WGP_JOB
+#undef WGP_WAIT
+#undef WGP_LOAD1
+  // ---- combine the K halves through LDS, one slab per workgroup (as the base kernel)
+  __syncthreads();
+  {
+    float* red = reinterpret_cast<float*>(smem);          // [2][144][64]
+    if (kh == 1) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(m * 144 + t * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += red[(m * 144 + t * 16 + r) * 64 + lane];
+    }
+  }
+  const int s = layer * gridDim.x + blockIdx.x;
+  if (kh == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        a.ws[(((size_t)s * 9 + t) * a.CoP + co) * a.CiP + ci0 + l31] = acc[t][r];
+      }
+  }
+  if (cib == 0) {
+#pragma unroll
+    for (int c = 0; c < ZCH; ++c) {
+      float v = bpart[c];
+      v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+      if (xv == 0) a.wsb[(size_t)s * a.CoP + co0 + c * 16 + chl] = v;
+    }
+  }
+}
+
 // Fixed-order reduction of the slabs (same scheme as fdet_wgrad3x3.hip)
 struct WgX3Red { float* dW[MAXL]; float* db[MAXL]; };
 __global__ void __launch_bounds__(1024)
@@ -386,7 +727,7 @@ k_wgx3_reduce(const float* __restrict__ ws_all, const float* __restrict__ wsb_al
 
 unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
-struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw, NSEG, CW, pack; size_t lds, ws_floats; bool ok; };
+struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw, NSEG, CW, pack, pipe; size_t lds, ws_floats; bool ok; };
 
 WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   WgX3Plan p{};
@@ -424,6 +765,15 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
     if (cost <= bestC * 1.0001) { bestC = cost; bestR = r; }
   }
   if (bestR == 0) { p.ok = false; bestR = 1; }
+  // pipelined kernel: 64 output channels, bands of exactly 128 positions (R = 128 / P rows = the rows one
+  // register set holds), two LDS tiles.  FDET_WGRAD_PIPE=0 keeps the single-tile kernel.
+  {
+    const char* e = getenv("FDET_WGRAD_PIPE");
+    const int rp = 32 / (4 * p.vw);
+    p.pipe = p.ok && p.MTC == 2 && p.NSEG == 1 && !p.pack && p.vw != 2 && rp * p.P == 128 && rows_total >= rp &&
+             (size_t)N * std::max(Cin, Cout) * H * W < ((size_t)1 << 29) && !(e && e[0] == '0');   // 32-bit byte offsets
+    if (p.pipe) bestR = rp;      // -> Kext 144, QZ 168, PX 152 + 2 P: the kernel's compile-time geometry
+  }
   p.R = bestR;
   const int Q = p.R * p.P;
   p.Kext = (Q + 9 + 15) / 16 * 16;
@@ -434,6 +784,7 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   p.nblk = (int)std::max(1L, std::min((long)p.nbands * p.NSEG, slots));
   p.lds = ((size_t)p.MTC * 32 * p.QZ + 32 * (size_t)p.PX) * 4;
   p.lds = std::max(p.lds, (size_t)p.MTC * 144 * 64 * 4);
+  if (p.pipe) p.lds = 2 * (((size_t)64 * p.QZ + 32 * (size_t)p.PX) * 4);
   p.ws_floats = (size_t)L * ((size_t)p.nblk * 9 * p.CoP * p.CiP + (size_t)p.nblk * p.CoP);
   return p;
 }
@@ -444,7 +795,18 @@ void launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) 
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
     hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds, st, a);
   };
-  if (p.NSEG > 1) go(k_wgrad3x3_x3<MTC, 4, true>);
+  if (p.pipe && MTC == 2) {
+#ifdef FDET_WG_DBG
+    const char* e = getenv("FDET_WG_DBG");
+    const int dbg = e ? atoi(e) : 0;
+#define WG_DBG_CASE(D) if (dbg == D) { if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4, D>); else go(k_wgrad3x3_x3_pipe<1, D>); return; }
+    WG_DBG_CASE(1) WG_DBG_CASE(3) WG_DBG_CASE(8) WG_DBG_CASE(9) WG_DBG_CASE(24) WG_DBG_CASE(40) WG_DBG_CASE(73)
+#endif
+    // (two-float rows: hipcc spills accumulators around the 64-bit staging tuples -> those shapes stay on the
+    // single-tile kernel)
+    if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4>);
+    else go(k_wgrad3x3_x3_pipe<1>);
+  } else if (p.NSEG > 1) go(k_wgrad3x3_x3<MTC, 4, true>);
   else if (p.pack) go(k_wgrad3x3_x3<MTC, 4, false, true>);
   else if (p.vw == 4) go(k_wgrad3x3_x3<MTC, 4, false>);
   else if (p.vw == 2) go(k_wgrad3x3_x3<MTC, 2, false>);
