@@ -9,6 +9,8 @@
 // stride-8 of the conv turns into the natural 8-element fragment granularity).
 // Weights live in registers for the whole kernel (30 rows x (hi,lo) x 4 VGPRs = 240 per lane).
 #include "fdet_common.h"
+#include <cstdlib>
+#include <utility>
 
 using namespace fdet;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -125,6 +127,179 @@ k_stem_fwd_x3(const StemX3Args a) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pipelined forward (same tiles, arithmetic and results): TWO LDS tiles and contiguous output rows
+// per workgroup.  While the 90 MFMAs of output row b run on tile b & 1, the hi/lo split + LDS writes
+// of row b+1 (its 30 input rows already in registers) ride one float4 per MFMA k-step, and the
+// global loads of row b+3 follow four steps behind the job that freed their register: asm buffer
+// loads (branch-free: padded / out-of-image elements are out-of-range offsets that return zero)
+// into two register sets, one in accumulation registers, one in arch VGPRs, waited for with a
+// counted vmcnt one whole row later (the 16 output stores of a row count in that queue too).
+// See the pipelined weight gradient (fdet_wgrad3x3_x3.hip) for why the staging must not be a
+// burst: a wave issues in order, and a burst of loads / LDS writes keeps it from issuing MFMAs.
+// ---------------------------------------------------------------------------------------
+// compile-time loop: the body sees its index as a constant expression, so register arrays indexed by it
+// are promoted to registers before any unrolling decision (asm outputs into a stack array would be
+// stored to scratch right behind the asm load, before the data has landed)
+template <int... I, class F>
+__device__ __forceinline__ void sx_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sx_static_for(F&& f) { sx_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+#define SX_LAMBDA(I) [&](auto I) __attribute__((always_inline))
+
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+template <bool AG>
+__device__ __forceinline__ void sx_aload(f32x4& d, unsigned off, const u32x4s& rs) {
+  if constexpr (AG) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(d) : "v"(off), "s"(rs));
+  else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d) : "v"(off), "s"(rs));
+}
+template <bool AG>
+__device__ __forceinline__ void sx_apass(f32x4& d) {
+  if constexpr (AG) asm volatile("" : "+a"(d)); else asm volatile("" : "+v"(d));
+}
+__device__ __forceinline__ void sx_split_pair(float f0, float f1, unsigned& hi, unsigned& lo) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t h = {(__bf16)f0, (__bf16)f1};
+  hi = __builtin_bit_cast(unsigned, h);
+  const f32x2_t hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+  const f32x2_t l = f32x2_t{f0, f1} - hf;
+  const bf16x2_t lb = {(__bf16)l[0], (__bf16)l[1]};
+  lo = __builtin_bit_cast(unsigned, lb);
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_stem_fwd_x3_pipe(const StemX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE = NROW * RL * 2;                   // bf16 elements per tile: hi rows, then lo rows
+  __bf16* const base = reinterpret_cast<__bf16*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int m = wid & 1, nt = wid >> 1;
+  const int cob = blockIdx.y;
+  const int co = cob * 64 + m * 32 + l31;
+  const int jmax = a.W / 4;
+  float* const sbias = reinterpret_cast<float*>(smem + 2 * TILE * 2);      // 64 floats behind the tiles
+  {
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    for (int t = tid; t < 2 * TILE * 2 / 16; t += 256) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) sbias[tid] = cob * 64 + tid < a.F ? a.bias[cob * 64 + tid] : 0.f;
+  }
+  bf16x8 ah[NROW], al[NROW];
+#pragma unroll
+  for (int rr = 0; rr < NROW; ++rr) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kx = 8 * half + j - 2;
+      const float f = (co < a.F && kx >= 0 && kx < KS) ? a.w[((size_t)co * CIN * KS + rr) * KS + kx] : 0.f;
+      const __bf16 h = (__bf16)f;
+      ah[rr][j] = h;
+      al[rr][j] = (__bf16)(f - (float)h);
+    }
+  }
+  const unsigned long long pa = (unsigned long long)a.x;
+  const u32x4s rx = {(unsigned)pa, (unsigned)(pa >> 32), (unsigned)(a.N * CIN * a.H * a.W) * 4u, 0x00020000u};
+  // staging slot s of a thread: input row rr = (s*256 + tid) >> 7, float4 j = (s*256 + tid) & 127 -> rr = 2s + (tid >> 7)
+  const int j4 = tid & 127, rsub = tid >> 7;
+  const bool lane_ok = j4 < jmax;
+  f32x4 p0[NSLOT], p1[NSLOT];
+  // load slot SL of output row (RN, ROY) into register SL of set S; ROY < 0: nothing (zeros)
+#define SXP_LOAD1(S, SL, RN, ROY)                                                               \
+  {                                                                                             \
+    const int irow_ = 2 * (SL) + rsub;                                                          \
+    const int ci = irow_ / KS, ky = irow_ - ci * KS;                                            \
+    const int iy = (ROY) * ST - PD + ky;                                                        \
+    const bool ok = lane_ok & ((ROY) >= 0) & (iy >= 0) & (iy < a.H);                           \
+    const unsigned off = ((unsigned)(((RN) * CIN + ci) * a.H + iy) * a.W + j4 * 4) * 4u;       \
+    sx_aload<S == 0>(p##S[SL], ok ? off : 0x80000000u, rx);                                     \
+  }
+#define SXP_WAIT(S, NKEEP)                                                                      \
+  {                                                                                             \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKEEP));                                           \
+    sx_static_for<NSLOT>(SX_LAMBDA(s_) { sx_apass<S == 0>(p##S[s_]); });                        \
+  }
+  // lanes past the row's width hold zeros and write them into the row's (zero) right pad
+#define SXP_JOB(S, SL, TB)                                                                      \
+  {                                                                                             \
+    __bf16* d_ = base + (TB) * TILE + (2 * (SL) + rsub) * RL + 4 + 4 * j4;                      \
+    unsigned h0, l0, h1, l1;                                                                    \
+    sx_split_pair(p##S[SL][0], p##S[SL][1], h0, l0); sx_split_pair(p##S[SL][2], p##S[SL][3], h1, l1); \
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));                               \
+    *reinterpret_cast<u32x2_t*>(d_) = u32x2_t{h0, h1};                                          \
+    *reinterpret_cast<u32x2_t*>(d_ + NROW * RL) = u32x2_t{l0, l1};                              \
+  }
+  const int bpw = (a.nrows + (int)gridDim.x - 1) / (int)gridDim.x;
+  int row = blockIdx.x * bpw;
+  const int last = min(row + bpw, a.nrows);
+#define SXP_NOY(R_, N_, OY_) const int N_ = (R_) / a.Ho; const int OY_ = (R_) < last ? (R_) - N_ * a.Ho : -1;
+  {
+    SXP_NOY(row, n_, oy_)
+    sx_static_for<NSLOT>(SX_LAMBDA(s) { SXP_LOAD1(0, s, n_, oy_) });
+  }
+  SXP_WAIT(0, 0)
+  __syncthreads();                                       // zero fill done
+  sx_static_for<NSLOT>(SX_LAMBDA(s) { SXP_JOB(0, s, 0) });
+  {
+    SXP_NOY(row + 1, n_, oy_)
+    sx_static_for<NSLOT>(SX_LAMBDA(s) { SXP_LOAD1(1, s, n_, oy_) });
+  }
+  {
+    SXP_NOY(row + 2, n_, oy_)
+    sx_static_for<NSLOT>(SX_LAMBDA(s) { SXP_LOAD1(0, s, n_, oy_) });
+  }
+  __syncthreads();
+  const int ox = nt * 32 + l31;
+  // one output row on tile PAR; jobs of the next row from set S = PAR ^ 1 into tile S.  In the memory queue at
+  // the wait, oldest first: set S loads, the previous row's 16 stores, set PAR loads  ->  keep 16 + NSLOT.
+  // (The very first wait sees no stores behind set S: keeping more than are pending is a no-op.)
+#define SXP_BAND(PAR, S)                                                                        \
+  {                                                                                             \
+    const int n = row / a.Ho, oy = row - n * a.Ho;                                              \
+    SXP_NOY(row + 3, n3_, oy3_)                                                                 \
+    const bf16x8* Bh = reinterpret_cast<const bf16x8*>(base + (PAR) * TILE) + nt * 32 + l31 + half; \
+    const bf16x8* Bl = Bh + NROW * RC;                                                          \
+    f32x16 acc;                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                \
+    bf16x8 bh[2], bl[2];                                                                        \
+    bh[0] = Bh[0]; bl[0] = Bl[0];                                                               \
+    SXP_WAIT(S, 16 + NSLOT)                                                                     \
+    sx_static_for<NROW>(SX_LAMBDA(rr_) {                                                        \
+      constexpr int rr = rr_;                                                                   \
+      constexpr int cur = rr & 1, nxt = cur ^ 1;                                                \
+      if (rr + 1 < NROW) { bh[nxt] = Bh[(rr + 1) * RC]; bl[nxt] = Bl[(rr + 1) * RC]; }          \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bl[cur], acc, 0, 0, 0);             \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bh[cur], acc, 0, 0, 0);             \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bh[cur], acc, 0, 0, 0);             \
+      if constexpr (rr < NSLOT) SXP_JOB(S, rr, S)                                               \
+      if constexpr (rr >= 4 && rr - 4 < NSLOT) SXP_LOAD1(S, rr - 4, n3_, oy3_)                  \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+    });                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                            \
+      const int c2 = cob * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;                     \
+      const bool ok = ox < a.Wo && c2 < a.F;                                                    \
+      const unsigned off = ok ? ((unsigned)((n * a.F + c2) * a.Ho + oy) * a.Wo + ox) * 4u : 0x80000000u; \
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[r] + sbias[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half]), ry, off, 0, 0); \
+    }                                                                                           \
+    __syncthreads();                                                                            \
+    row += 1;                                                                                   \
+  }
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.N * a.F * a.Ho * a.Wo * 4, 0x00020000);
+  while (row < last) {
+    SXP_BAND(0, 1)
+    if (row >= last) break;
+    SXP_BAND(1, 0)
+  }
+  SXP_WAIT(0, 0)
+  SXP_WAIT(1, 0)
+#undef SXP_BAND
+#undef SXP_NOY
+#undef SXP_JOB
+#undef SXP_WAIT
+#undef SXP_LOAD1
 }
 
 // ---------------------------------------------------------------------------------------
@@ -350,6 +525,13 @@ int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int
   const int FP = (F + 63) / 64 * 64;
   const int nblk = a.nrows < 256 ? a.nrows : 256;
   const size_t lds = (size_t)NROW * RL * 2 * 2;
+  const char* e = getenv("FDET_STEM_PIPE");
+  // pipelined kernel: 32-bit byte offsets into x and y (FDET_STEM_PIPE=0 keeps the single-tile kernel)
+  if (!(e && e[0] == '0') && (size_t)N * CIN * H * W < ((size_t)1 << 29) && (size_t)N * F * a.Ho * a.Wo < ((size_t)1 << 29)) {
+    (void)hipFuncSetAttribute((const void*)k_stem_fwd_x3_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds + 256));
+    hipLaunchKernelGGL(k_stem_fwd_x3_pipe, dim3(nblk, FP / 64), dim3(256), 2 * lds + 256, st, a);
+    return check_launch("fdet_stem_fwd(bf16x3 pipelined)");
+  }
   (void)hipFuncSetAttribute((const void*)k_stem_fwd_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_stem_fwd_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
   return check_launch("fdet_stem_fwd(bf16x3)");
