@@ -251,11 +251,11 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
     SXP_NOY(row + 2, n_, oy_)
     sx_static_for<NSLOT>(SX_LAMBDA(s) { SXP_LOAD1(0, s, n_, oy_) });
   }
+  SXP_WAIT(1, NSLOT)                                     // first band: no stores queued behind set 1 yet, its counted wait would let it pass
   __syncthreads();
   const int ox = nt * 32 + l31;
   // one output row on tile PAR; jobs of the next row from set S = PAR ^ 1 into tile S.  In the memory queue at
   // the wait, oldest first: set S loads, the previous row's 16 stores, set PAR loads  ->  keep 16 + NSLOT.
-  // (The very first wait sees no stores behind set S: keeping more than are pending is a no-op.)
 #define SXP_BAND(PAR, S)                                                                        \
   {                                                                                             \
     const int n = row / a.Ho, oy = row - n * a.Ho;                                              \
@@ -546,6 +546,9 @@ int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* 
   const int nblk = a.nrows < 256 ? a.nrows : 256;
   a.ws = ws; a.wsb = ws + (size_t)nblk * FP * 320;
   const size_t lds = ((size_t)NPLANE * PE * 2 + 64 * DL * 2) * 2;
+  // Tried and dropped: two bands of prefetch in flight.  With compiler-visible buffer loads (loop unrolled by
+  // two) the time did not move (0.327 ms): the kernel is not latency-bound; with asm loads into reserved
+  // registers hipcc copied the just-loaded tuples before the data landed (tools/audit_asm_loads.py).
   (void)hipFuncSetAttribute((const void*)k_stem_wgrad_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_stem_wgrad_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
   if (int rc = check_launch("fdet_stem_wgrad(bf16x3)")) return rc;
