@@ -3,6 +3,13 @@
 // staging / epilogue runs beside the other's MFMAs.  Fastest for rows of <= 64 columns (the
 // PoolResnet resolutions); anything it has no tiling for goes to the general persistent kernel
 // (fdet_conv3x3_x3_kernel.inc).  Same arithmetic, LDS layout and epilogue fusion modes as described there.
+//
+// Tried and dropped (round 1): the woven one-workgroup-per-CU pipeline that pays for the weight gradient and
+// the stem (two LDS chunk buffers, one staging job / asm buffer load per group of four MFMAs, counted
+// vmcnt).  Bit-identical results, no gain at 60x60 (fwd 0.31 vs 0.25 ms per launch in tools/probe/conv_dbg.py
+// terms): ablation gave MFMA loop alone 0.18, + staging jobs and loads +0.085, + epilogue +0.055 -- every
+// part ADDS even when woven (the LDS store path and the wave's single issue stream are shared with the
+// fragment reads), and only a second co-resident workgroup overlaps the epilogue.
 #include "fdet_conv_common.h"
 #include <algorithm>
 #include <cstdint>
@@ -164,7 +171,17 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
   bf16x8* lds = reinterpret_cast<bf16x8*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  int tile = blockIdx.x;
+  // XCD-aware persistent walk: blockIdx round-robins over the 8 XCDs (private L2 each), so workgroups with the same
+  // blockIdx % 8 take one contiguous eighth of the tiles, neighbours in it at the same time -- the two halo rows a
+  // band shares with the next one are then re-read from that XCD's L2 instead of HBM.
+  int tile = blockIdx.x, tend = p.ntiles, tstep = gridDim.x;
+  if (gridDim.x % 8 == 0) {
+    const int grp = blockIdx.x & 7, chunk = (p.ntiles + 7) >> 3;
+    tile = grp * chunk + (blockIdx.x >> 3);
+    tend = min((grp + 1) * chunk, p.ntiles);
+    tstep = gridDim.x >> 3;
+    if (tile >= tend) tile = tend = p.ntiles;          // no tile for this workgroup
+  }
   int mb = tile % p.ncob;
   int v0 = (tile / p.ncob) * a.R;
   const int H1 = a.H + 1;
@@ -262,7 +279,7 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
 
   const int nch = a.Cin / CK16;
   bool first = true;
-  for (; tile < p.ntiles; tile += gridDim.x) {
+  for (; tile < tend; tile += tstep) {
   const int cur_v0 = v0, cur_mb = mb;    // the tile whose chunks are consumed below
   for (int c = 0; c < nch; ++c) {
     const bf16x8* buf = lds;
@@ -272,9 +289,9 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     __syncthreads();
     if (c + 1 < nch) {
       X3_ISSUE_LOADS(c + 1)
-    } else if (tile + (int)gridDim.x < p.ntiles) {
+    } else if (tile + tstep < tend) {
       // the next tile's first chunk travels during this tile's last MFMA block and its epilogue
-      const int nt_ = tile + gridDim.x;
+      const int nt_ = tile + tstep;
       mb = nt_ % p.ncob;
       v0 = (nt_ / p.ncob) * a.R;
       X3_TILE_SRC(v0)

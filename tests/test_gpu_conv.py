@@ -24,6 +24,8 @@ def close(a, b, tol=1e-4):
 
 SHAPES = [(3, 64, 60, 60), (5, 64, 15, 15), (4, 64, 30, 30), (2, 32, 30, 30), (2, 8, 7, 9), (1, 16, 20, 20),
           (2, 128, 15, 15), (33, 64, 15, 15),
+          # pipelined weight gradient edge cases: one image (odd band count), idle column lanes (W=56), short odd rows
+          (1, 64, 60, 56), (2, 64, 9, 13), (7, 64, 6, 60),
           # wide rows (Resnet at 480^2 / 640^2): column-segmented tiles in the bf16x3 kernels
           (1, 64, 12, 240), (1, 32, 9, 320), (2, 64, 20, 100), (1, 16, 6, 164), (2, 64, 17, 80)]
 
@@ -82,6 +84,25 @@ def test_conv3x3_fwd_dgrad_wgrad(hp, shape, x3):
     F.conv2d(xr, wr, br, padding=1).backward(dz)
     close(dW, wr.grad)
     close(db, br.grad)
+
+
+@pytest.mark.parametrize("cfg", [(3, 4, 64, 15, 15), (2, 2, 64, 60, 60), (16, 2, 64, 15, 15), (2, 3, 64, 30, 30), (2, 2, 32, 20, 20)])
+def test_conv3x3_wgrad_batched(hp, cfg):
+    """L same-shape layers in ONE launch (the bench path: 2 layers at 60x60, 4 at 30x30, 16 at 15x15) against
+    autograd per layer; 1e-4 of the tensor's scale as everywhere."""
+    L, N, C, H, W = cfg
+    g = torch.Generator().manual_seed(L * 100 + H)
+    xs = [torch.randn(N, C, H, W, generator=g) for _ in range(L)]
+    dzs = [torch.randn(N, C, H, W, generator=g) for _ in range(L)]
+    dWs = [torch.full((C, C, 3, 3), float("nan"), device="cuda") for _ in range(L)]
+    dbs = [torch.full((C,), float("nan"), device="cuda") for _ in range(L)]
+    ws = torch.empty(hp.conv3x3_wgrad_batched_ws_bytes(L, N, C, C, H, W) // 4, device="cuda")
+    hp.conv3x3_wgrad_batched([x.cuda() for x in xs], [d.cuda() for d in dzs], dWs, dbs, ws)
+    for l in range(L):
+        wr = torch.zeros(C, C, 3, 3, requires_grad=True); br = torch.zeros(C, requires_grad=True)
+        F.conv2d(xs[l], wr, br, padding=1).backward(dzs[l])
+        close(dWs[l], wr.grad)
+        close(dbs[l], br.grad)
 
 
 @pytest.mark.parametrize("pool", [1, 2])
