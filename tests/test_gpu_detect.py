@@ -1,6 +1,7 @@
 """GPU parity of the detection math (encode, loss, decode, NMS, metrics, normalise, Adam),
 called through the C-ABI and checked against the oracle / golden fixtures.
 Bit-exact for index/integer-valued work; fp32 loss within 1e-4 (north-star tolerance)."""
+import math
 import pytest
 import torch
 
@@ -102,6 +103,31 @@ def test_nms_keep_sets_bit_exact(hp, thr):
         keep = hp.nms(boxes=boxes.cuda(), scores=scores.cuda(), iou_threshold=thr).cpu()
         assert keep.tolist() == O.nms(boxes, scores, thr).tolist(), K
     assert hp.nms(torch.zeros(0, 4).cuda(), torch.zeros(0).cuda(), thr).numel() == 0
+
+
+def _config5_candidates(B, K, seed=2, size=480):
+    """K candidates per image, scores U(0,1), centres uniform, sizes log-uniform 8..128 px."""
+    g = torch.Generator().manual_seed(seed)
+    c = torch.rand(B, K, 2, generator=g) * size
+    wh = torch.exp(torch.rand(B, K, 2, generator=g) * (math.log(128.0) - math.log(8.0)) + math.log(8.0))
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 2).round()
+    scores = torch.rand(B, K, generator=g)
+    return boxes, scores
+
+
+@pytest.mark.parametrize("K", [1024, 4096])
+def test_batched_nms_config5(hp, K):
+    """Batched greedy NMS at K >= 1000 candidates per image (config 5's synthetic distribution), ragged counts:
+    every image's keep list equals the oracle's (restated torchvision semantics, PARITY UNPINNED by the reference)."""
+    B = 6
+    boxes, scores = _config5_candidates(B, K)
+    counts = torch.tensor([K, K - 1, K // 2, 1, 0, K], dtype=torch.int32)
+    keep, kc = hp.nms_batched(boxes.cuda(), scores.cuda(), counts.cuda(), 0.5)
+    keep, kc = keep.cpu(), kc.cpu()
+    for b in range(B):
+        n = int(counts[b])
+        ref = O.nms(boxes[b, :n], scores[b, :n], 0.5).tolist() if n else []
+        assert keep[b, : int(kc[b])].tolist() == ref, (K, b)
 
 
 def test_reduce_roundtrip_full_batch(hp):
