@@ -419,16 +419,19 @@ __device__ __forceinline__ void apass(T& d) {
 // their LDS writes, 32 jobs without the split arithmetic, 64 non-zero initial tiles.  Measured with them on the
 // 60x60 layers (ms per launch incl. reduce): MFMA alone on zero tiles 0.350, on non-zero tiles 0.405 (clock),
 // + L2-resident loads +0.00, + split VALU +0.04, + LDS writes +0.04, + real HBM traffic +0.07 -> 0.56.
-template <int VW, int DBG = 0>
+// LPR = lanes per staged row (16, or 32 for one-float lanes of rows up to 32 columns: the 30x30 layers -- their
+// two-float form made hipcc spill accumulators around the 64-bit staging tuples); P = LPR * VW.
+template <int VW, int DBG = 0, int LPR = 16>
 __global__ void __launch_bounds__(NTHR, 1)
 k_wgrad3x3_x3_pipe(const WgX3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int MTC = 2, MB = 64, ZCH = 4, XCH = 2;
-  constexpr int RZ = 32 / (ZCH * VW);                  // dz rows per band held in registers (= R)
+  constexpr int CPP = NTHR / LPR;                      // channels per staging pass (16 or 8)
+  constexpr int MTC = 2, MB = 64, ZCH = MB / CPP, XCH = 32 / CPP;
+  constexpr int RZ = 128 / (LPR * VW);                  // dz rows per band held in registers (= R)
   constexpr int RX = RZ + 2;
   using VT = typename Vec<VW>::T;
   // compile-time tile geometry (plan_x3 computes the same numbers; the launcher checks them)
-  constexpr int P = 16 * VW, R = RZ, KEXT = 144, QZ = KEXT + 24, PX = KEXT + 2 * P + 8;
+  constexpr int P = LPR * VW, R = RZ, KEXT = 144, QZ = KEXT + 24, PX = KEXT + 2 * P + 8;
   static_assert(R * P == 128 && (QZ / 8) % 2 == 1 && (PX / 8) % 2 == 1, "band = 128 positions, odd 16-byte row pitches");
   constexpr int tile_elems = MB * QZ * 2 + 32 * PX * 2;          // bf16 elements per tile (hi + lo, Z then X)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -451,7 +454,7 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   constexpr int p8 = P / 8;
-  const int xv = tid & 15, chl = tid >> 4;
+  const int xv = tid & (LPR - 1), chl = tid / LPR;
   const bool lane_ok = xv < W / VW;
   const int co0 = cob * MB, ci0 = cib * 32;
   const int HW = a.H * W;
@@ -464,9 +467,9 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
   unsigned zch_off[ZCH], xch_off[XCH];
   bool zch_ok[ZCH], xch_ok[XCH];
 #pragma unroll
-  for (int c = 0; c < ZCH; ++c) { zch_off[c] = (unsigned)(co0 + c * 16 + chl) * HW * 4u; zch_ok[c] = co0 + c * 16 + chl < a.Cout; }
+  for (int c = 0; c < ZCH; ++c) { zch_off[c] = (unsigned)(co0 + c * CPP + chl) * HW * 4u; zch_ok[c] = co0 + c * CPP + chl < a.Cout; }
 #pragma unroll
-  for (int c = 0; c < XCH; ++c) { xch_off[c] = (unsigned)(ci0 + c * 16 + chl) * HW * 4u; xch_ok[c] = ci0 + c * 16 + chl < a.Cin; }
+  for (int c = 0; c < XCH; ++c) { xch_off[c] = (unsigned)(ci0 + c * CPP + chl) * HW * 4u; xch_ok[c] = ci0 + c * CPP + chl < a.Cin; }
   // two register sets, used alternately (0: accumulation registers, 1: arch VGPRs): register l of a set is
   // re-loaded (band + 2) a few slots after job l staged it, so every load has more than one whole band of
   // MFMAs to land
@@ -507,30 +510,31 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
       _Pragma("unroll") for (int r_ = 2; r_ < RX; ++r_) apass<S == 0>(px##S[c_][r_]);             \
   }
   // staging job J (0 .. NJ-1) of the band in set S into tile TB; branch-free: the 16 lanes of a row cover its
-  // whole pitch (16 * VW = P), lanes past the row's width hold zeros (their loads are out of range) and
+  // whole pitch (LPR * VW = P), lanes past the row's width hold zeros (their loads are out of range) and
   // write them into the pad columns, which must be zero anyway
 #define WGP_JOB(S, J, TB)                                                                         \
   {                                                                                               \
     __bf16* tb_ = base + (TB) * tile_elems;                                                       \
     if ((J) < NZJ) {                                                                              \
       const int c_ = (J) / RZ, r_ = (J) % RZ;                                                 \
-      __bf16* zh_ = tb_ + (c_ * 16 + chl) * QZ + ZP + r_ * P + xv * VW;                         \
+      __bf16* zh_ = tb_ + (c_ * CPP + chl) * QZ + ZP + r_ * P + xv * VW;                         \
       put_split_pk<VW, DBG>(zh_, zh_ + MB * QZ, pz##S[c_][r_]);                                            \
       _Pragma("unroll") for (int k_ = 0; k_ < VW; ++k_) bpart[c_] += vget<VW>(pz##S[c_][r_], k_); \
     } else {                                                                                      \
       const int j2_ = (J) - NZJ < NXJ ? (J) - NZJ : 0;                                        \
       const int c_ = j2_ / RZ, r_ = 2 + j2_ % RZ;                                                 \
-      __bf16* xh_ = tb_ + 2 * MB * QZ + (c_ * 16 + chl) * PX + XP + r_ * P + xv * VW;         \
+      __bf16* xh_ = tb_ + 2 * MB * QZ + (c_ * CPP + chl) * PX + XP + r_ * P + xv * VW;         \
       put_split_pk<VW, DBG>(xh_, xh_ + 32 * PX, px##S[c_][r_]);                                            \
     }                                                                                             \
   }
   // operand fragments of one 16-position MFMA step, two sets (the reads of step s+1 are issued inside step s)
   bf16x8 fz[2][6], fb[2][6];
-  // halo copy: 64 x rows (32 channels, hi and lo) x 2P elements = VW 16-byte chunks per thread
-  bf16x8 cpy[VW];
-  int cp_off[VW];
+  // halo copy: 64 x rows (32 channels, hi and lo) x 2P elements = NCP 16-byte chunks per thread
+  constexpr int NCP = P / 16, CPR = P / 4;            // chunks per thread, chunks per x row
+  bf16x8 cpy[NCP];
+  int cp_off[NCP];
 #pragma unroll
-  for (int i = 0; i < VW; ++i) { const int q = tid + NTHR * i; cp_off[i] = 2 * MB * QZ + (q / (4 * VW)) * PX + XP + (q % (4 * VW)) * 8; }
+  for (int i = 0; i < NCP; ++i) { const int q = tid + NTHR * i; cp_off[i] = 2 * MB * QZ + (q / CPR) * PX + XP + (q % CPR) * 8; }
 #define WGP_FRAGS(F, TB, KS_)                                                                     \
   {                                                                                               \
     const __bf16* tb_ = base + (TB) * tile_elems;                                                 \
@@ -546,8 +550,8 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
   // slot U (0 .. 31: eight per MFMA step, behind tap groups 1..8) of a band: its jobs, then its loads
 #define WGP_SLOT(S, U, V0N)                                                                       \
   {                                                                                               \
-    if ((U) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < VW; ++i_) cpy[i_] = *reinterpret_cast<const bf16x8*>(base + (1 - (S)) * tile_elems + cp_off[i_] + RZ * P); } \
-    if ((U) == 2) { _Pragma("unroll") for (int i_ = 0; i_ < VW; ++i_) *reinterpret_cast<bf16x8*>(base + (S) * tile_elems + cp_off[i_]) = cpy[i_]; } \
+    if ((U) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < NCP; ++i_) cpy[i_] = *reinterpret_cast<const bf16x8*>(base + (1 - (S)) * tile_elems + cp_off[i_] + RZ * P); } \
+    if ((U) == 2) { _Pragma("unroll") for (int i_ = 0; i_ < NCP; ++i_) *reinterpret_cast<bf16x8*>(base + (S) * tile_elems + cp_off[i_]) = cpy[i_]; } \
     _Pragma("unroll") for (int q_ = 0; q_ < JPS; ++q_) {                                          \
       if (!(DBG & 1) && (U) * JPS + q_ < NJ) WGP_JOB(S, ((U) * JPS + q_ < NJ ? (U) * JPS + q_ : 0), S) \
     }                                                                                             \
@@ -606,7 +610,7 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
   for (int c = 0; c < XCH; ++c)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      __bf16* xh_ = base + 2 * MB * QZ + (c * 16 + chl) * PX + XP + r * P + xv * VW;
+      __bf16* xh_ = base + 2 * MB * QZ + (c * CPP + chl) * PX + XP + r * P + xv * VW;
       put_split<VW>(xh_, xh_ + 32 * PX, 0, hx[c][r]);
     }
 #pragma unroll
@@ -678,8 +682,9 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
 #pragma unroll
     for (int c = 0; c < ZCH; ++c) {
       float v = bpart[c];
+      if (LPR == 32) v += __shfl_xor(v, 16, 32);
       v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
-      if (xv == 0) a.wsb[(size_t)s * a.CoP + co0 + c * 16 + chl] = v;
+      if (xv == 0) a.wsb[(size_t)s * a.CoP + co0 + c * CPP + chl] = v;
     }
   }
 }
@@ -727,7 +732,7 @@ k_wgx3_reduce(const float* __restrict__ ws_all, const float* __restrict__ wsb_al
 
 unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
-struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw, NSEG, CW, pack, pipe; size_t lds, ws_floats; bool ok; };
+struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw, NSEG, CW, pack, pipe, lpr32; size_t lds, ws_floats; bool ok; };
 
 WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   WgX3Plan p{};
@@ -770,9 +775,11 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   {
     const char* e = getenv("FDET_WGRAD_PIPE");
     const int rp = 32 / (4 * p.vw);
-    p.pipe = p.ok && p.MTC == 2 && p.NSEG == 1 && !p.pack && p.vw != 2 && rp * p.P == 128 && rows_total >= rp &&
+    const bool lpr32 = p.P == 32 && p.NSEG == 1 && !p.pack && W <= 32;      // one-float lanes, 32 per row (30x30)
+    p.pipe = p.ok && p.MTC == 2 && p.NSEG == 1 && !p.pack && ((p.vw != 2 && rp * p.P == 128) || lpr32) && rows_total >= 8 &&
              (size_t)N * std::max(Cin, Cout) * H * W < ((size_t)1 << 29) && !(e && e[0] == '0');   // 32-bit byte offsets
-    if (p.pipe) bestR = rp;      // -> Kext 144, QZ 168, PX 152 + 2 P: the kernel's compile-time geometry
+    p.lpr32 = p.pipe && lpr32;
+    if (p.pipe) bestR = p.lpr32 ? 4 : rp;      // -> Kext 144, QZ 168, PX 152 + 2 P: the kernel's compile-time geometry
   }
   p.R = bestR;
   const int Q = p.R * p.P;
@@ -799,12 +806,11 @@ void launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) 
 #ifdef FDET_WG_DBG
     const char* e = getenv("FDET_WG_DBG");
     const int dbg = e ? atoi(e) : 0;
-#define WG_DBG_CASE(D) if (dbg == D) { if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4, D>); else go(k_wgrad3x3_x3_pipe<1, D>); return; }
+#define WG_DBG_CASE(D) if (dbg == D && !p.lpr32) { if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4, D>); else go(k_wgrad3x3_x3_pipe<1, D>); return; }
     WG_DBG_CASE(1) WG_DBG_CASE(3) WG_DBG_CASE(8) WG_DBG_CASE(9) WG_DBG_CASE(24) WG_DBG_CASE(40) WG_DBG_CASE(73)
 #endif
-    // (two-float rows: hipcc spills accumulators around the 64-bit staging tuples -> those shapes stay on the
-    // single-tile kernel)
-    if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4>);
+    if (p.lpr32) go(k_wgrad3x3_x3_pipe<1, 0, 32>);
+    else if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4>);
     else go(k_wgrad3x3_x3_pipe<1>);
   } else if (p.NSEG > 1) go(k_wgrad3x3_x3<MTC, 4, true>);
   else if (p.pack) go(k_wgrad3x3_x3<MTC, 4, false, true>);
