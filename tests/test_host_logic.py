@@ -42,6 +42,32 @@ def test_default_init_equals_reference_init_order():
         assert torch.equal(v, P[k]), k
 
 
+def test_lightning_style_checkpoint_round_trip(tmp_path):
+    """the reference restores training state with
+    `ModelMeta(model=model).load_state_dict(checkpoint["state_dict"])` (demo_scripts/convert_checkpoint_to_scripted_model.py:32-40,
+    load_checkpoint.py:22) -- Lightning keys carry the `model.` prefix.  The mirror's ModelMeta has the same key set, and a
+    checkpoint written in that layout loads back through a loader that executes nothing from the file."""
+    from fdet_amd.models import ModelMeta
+    torch.manual_seed(1)
+    src = ModelMeta(model=PoolResnet(8, (3, 480, 480), 10), lr=1e-4)
+    keys = list(src.state_dict().keys())
+    assert keys == ["model." + k for k in param_names(10)]
+    path = tmp_path / "epoch=0-step=1.ckpt"
+    torch.save({"state_dict": src.state_dict(), "epoch": 0, "global_step": 1}, path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    torch.manual_seed(2)
+    dst = ModelMeta(model=PoolResnet(8, (3, 480, 480), 10), lr=1e-4)
+    assert not torch.equal(dst.state_dict()["model.conv1.weight"], src.state_dict()["model.conv1.weight"])
+    res = dst.load_state_dict(ck["state_dict"])
+    assert not res.missing_keys and not res.unexpected_keys
+    for k in keys:
+        assert torch.equal(dst.state_dict()[k], src.state_dict()[k]), k
+    # the bare model takes the same tensors with the prefix stripped (how the demos hand weights to BaseModel)
+    bare = PoolResnet(8, (3, 480, 480), 10)
+    bare.load_state_dict({k[len("model."):]: v for k, v in ck["state_dict"].items()})
+    assert torch.equal(bare.state_dict()["out.bias"], src.state_dict()["model.out.bias"])
+
+
 def test_product_path_has_no_cpu_fallback():
     from fdet_amd import FdetError
     m = PoolResnet(8, (3, 480, 480), 10).eval()
