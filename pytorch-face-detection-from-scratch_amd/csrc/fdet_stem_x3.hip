@@ -480,6 +480,212 @@ k_stem_wgrad_x3(const StemWgX3Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Pipelined weight gradient (same planes and slab layout): planes of 9 chunks (8 pad + 60 + slack) so that TWO
+// plane tiles fit LDS beside ONE dy tile; contiguous output rows per workgroup.  While the 60 MFMAs of row b
+// run on plane tile b & 1, the 32 pixel-pair split jobs of row b+1 ride two per (k-step, N tile) slot into the
+// other tile, the asm buffer loads of row b+2 follow four slots behind the jobs that freed their registers (ONE x
+// register set, counted waits per group of four slots), and the small dy tile of row b+1 -- loaded at the start of
+// row b -- is staged between the rows.  Every wave takes four aligned-tap N tiles and one
+// funnel-shifted one (tiles {0..3, 8} / {4..7, 9}), so there is a single code path.
+// ---------------------------------------------------------------------------------------
+constexpr int PCP = 9, PEP = PCP * 8;      // plane pitch of the pipelined kernel
+constexpr int TILEP = NPLANE * PEP * 2;    // bf16 elements per plane tile (hi planes, then lo planes)
+
+__global__ void __launch_bounds__(256, 1)
+k_stem_wgrad_x3_pipe(const StemWgX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* const base = reinterpret_cast<__bf16*>(smem);       // two plane tiles
+  __bf16* Dh = base + 2 * TILEP;                              // [64 co][DL]
+  __bf16* Dl = Dh + 64 * DL;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int m = wid & 1, ng = wid >> 1;
+  const int cob = blockIdx.y;
+  const int gmax = a.W / 16, dmax = a.Wo / 4;
+  {
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    for (int t = tid; t < (2 * TILEP + 2 * 64 * DL + 8 * PEP) * 2 / 16; t += 256) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // N tile t of this wave: t < 4 -> aligned taps tile ng*4 + t (kk = row*8 + kx-2); t == 4 -> shifted taps tile 8 + ng
+  int pbase[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    int plane, extra;
+    if (t < 4) { const int kk = min((ng * 4 + t) * 32 + l31, NROW * 8 - 1); plane = kk; extra = 1; }
+    else { const int kk2 = min(ng * 32 + l31, NROW * 2 - 1); plane = (kk2 >> 1) * 8 + 6 + (kk2 & 1); extra = 0; }
+    pbase[t] = plane * PCP + extra + half;
+  }
+  const bf16x8* Ah = reinterpret_cast<const bf16x8*>(Dh + (m * 32 + l31) * DL) + half;
+  const bf16x8* Al = reinterpret_cast<const bf16x8*>(Dl + (m * 32 + l31) * DL) + half;
+  f32x16 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bpart[4] = {0.f, 0.f, 0.f, 0.f};
+  // staging geometry of this thread (threads without a pixel group write their zeros into 8 junk planes)
+  int xw_off[WSLOT]; unsigned x_goff[WSLOT]; bool x_ok[WSLOT];
+#pragma unroll
+  for (int s_ = 0; s_ < WSLOT; ++s_) {
+    const int it = s_ * 256 + tid;
+    const int rr = it >> 5, g_ = it & 31;
+    x_ok[s_] = rr < NROW && g_ < gmax;
+    xw_off[s_] = x_ok[s_] ? (rr * 8) * PEP + 8 + 2 * g_ : -1;
+    x_goff[s_] = (unsigned)(g_ * 16) * 4u;
+  }
+  __bf16* const junk = Dl + 64 * DL + 2 * (tid & 31);
+  unsigned d_goff[4]; bool d_ok[4]; int dw_off[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    const int it = s_ * 256 + tid;
+    const int c = it >> 4, j = it & 15;
+    const int cg = cob * 64 + c;
+    d_ok[s_] = j < dmax && cg < a.F;
+    d_goff[s_] = ((unsigned)cg * a.Ho * a.Wo + j * 4) * 4u;
+    dw_off[s_] = c * DL + 4 * j;
+  }
+  const unsigned long long pa_x = (unsigned long long)a.x, pa_d = (unsigned long long)a.dy;
+  const u32x4s rsx = {(unsigned)pa_x, (unsigned)(pa_x >> 32), (unsigned)(a.N * CIN * a.H * a.W) * 4u, 0x00020000u};
+  const u32x4s rsd = {(unsigned)pa_d, (unsigned)(pa_d >> 32), (unsigned)(a.N * a.F * a.Ho * a.Wo) * 4u, 0x00020000u};
+  f32x4 px0[WSLOT][4], pd[4];       // ONE x register set (a slot is re-loaded right behind the jobs that read it) and the dy set
+  const int bpw = (a.nrows + (int)gridDim.x - 1) / (int)gridDim.x;
+  int row = blockIdx.x * bpw;
+  const int last = min(row + bpw, a.nrows);
+#define SWP_NOY(R_, N_, OY_) const int N_ = (R_) / a.Ho; const int OY_ = (R_) < last ? (R_) - N_ * a.Ho : -1;
+#define SWP_LOAD_X1(S, SL, Q, N_, OY_)                                                            \
+  {                                                                                               \
+    const int rr_ = ((SL) * 256 + tid) >> 5;                                                      \
+    const int rc_ = min(rr_, NROW - 1);                                                           \
+    const int ci_ = rc_ / KS, ky_ = rc_ - ci_ * KS;                                               \
+    const int iy_ = (OY_) * ST - PD + ky_;                                                        \
+    const bool ok_ = x_ok[SL] & ((OY_) >= 0) & (iy_ >= 0) & (iy_ < a.H);                          \
+    const unsigned off_ = ((unsigned)(((N_) * CIN + ci_) * a.H + iy_) * a.W) * 4u + x_goff[SL] + (Q) * 16; \
+    sx_aload<false>(px##S[SL][Q], ok_ ? off_ : 0x80000000u, rsx);                                \
+  }
+#define SWP_LOAD_D1(SL, N_, OY_)                                                                  \
+  {                                                                                               \
+    const unsigned off_ = ((unsigned)(((N_) * a.F) * a.Ho + (OY_)) * a.Wo) * 4u + d_goff[SL];     \
+    sx_aload<false>(pd[SL], (d_ok[SL] & ((OY_) >= 0)) ? off_ : 0x80000000u, rsd);                 \
+  }
+#define SWP_PASS_X(S) sx_static_for<WSLOT * 4>(SX_LAMBDA(l_) { sx_apass<false>(px##S[l_ / 4][l_ % 4]); });
+#define SWP_PASS_XS(SL) sx_static_for<4>(SX_LAMBDA(q_) { sx_apass<false>(px0[SL][q_]); });
+#define SWP_PASS_D() sx_static_for<4>(SX_LAMBDA(s_) { sx_apass<false>(pd[s_]); });
+  // pixel-pair job (SL, I): pixels i and i+8 of the thread's 16-pixel group -> plane row*8 + i of tile TB
+#define SWP_JOB(S, SL, I, TB)                                                                     \
+  {                                                                                               \
+    unsigned hi_, lo_;                                                                            \
+    sx_split_pair(px##S[SL][(I) >> 2][(I) & 3], px##S[SL][2 + ((I) >> 2)][(I) & 3], hi_, lo_);    \
+    __bf16* d_ = (xw_off[SL] >= 0 ? base + (TB) * TILEP + xw_off[SL] : junk) + (I) * PEP;         \
+    *reinterpret_cast<unsigned*>(d_) = hi_;                                                       \
+    *reinterpret_cast<unsigned*>(d_ + (xw_off[SL] >= 0 ? NPLANE * PEP : 0)) = lo_;                \
+  }
+  // dy tile (lanes past the row hold zeros and write them into the row's zero pad)
+#define SWP_STAGE_D()                                                                             \
+  sx_static_for<4>(SX_LAMBDA(s_) {                                                                \
+    unsigned h0, l0, h1, l1;                                                                      \
+    sx_split_pair(pd[s_][0], pd[s_][1], h0, l0); sx_split_pair(pd[s_][2], pd[s_][3], h1, l1);     \
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));                                 \
+    *reinterpret_cast<u32x2_t*>(Dh + dw_off[s_]) = u32x2_t{h0, h1};                               \
+    *reinterpret_cast<u32x2_t*>(Dl + dw_off[s_]) = u32x2_t{l0, l1};                               \
+    bpart[s_] += (pd[s_][0] + pd[s_][1]) + (pd[s_][2] + pd[s_][3]);                               \
+  });
+  {
+    SWP_NOY(row, n_, oy_)
+    sx_static_for<4>(SX_LAMBDA(s_) { SWP_LOAD_D1(s_, n_, oy_) });
+    sx_static_for<WSLOT * 4>(SX_LAMBDA(l_) { SWP_LOAD_X1(0, l_ / 4, l_ % 4, n_, oy_) });
+  }
+  asm volatile("s_waitcnt vmcnt(0)");
+  SWP_PASS_X(0)
+  SWP_PASS_D()
+  __syncthreads();                                       // zero fill done
+  sx_static_for<WSLOT * 8>(SX_LAMBDA(j_) { SWP_JOB(0, j_ / 8, j_ % 8, 0) });
+  SWP_STAGE_D()
+  {
+    SWP_NOY(row + 1, n_, oy_)
+    sx_static_for<WSLOT * 4>(SX_LAMBDA(l_) { SWP_LOAD_X1(0, l_ / 4, l_ % 4, n_, oy_) });
+  }
+  __syncthreads();
+  // one row on plane tile PAR.  Slot u = 5 ks + t.  In the memory queue at the top of a row, oldest first:
+  // [x of the next row: 16, issued under the previous row][dy of the next row: 4, issued first thing in this row];
+  // the jobs of slot group s (slots 4s..4s+3) read x loads 4s..4s+3, behind which sit 12 - 4s older-row loads,
+  // the 4 dy loads and the max(0, 4s - 4) re-loads already issued in this row.
+#define SWP_ROW(PAR)                                                                              \
+  {                                                                                               \
+    SWP_NOY(row + 2, n2_, oy2_)                                                                   \
+    SWP_NOY(row + 1, n1_, oy1_)                                                                   \
+    const bf16x8* Bh = reinterpret_cast<const bf16x8*>(base + (PAR) * TILEP);                     \
+    const bf16x8* Bl = reinterpret_cast<const bf16x8*>(base + (PAR) * TILEP + NPLANE * PEP);      \
+    bf16x8 fa[2][2], fb[2][4];                                                                    \
+    fa[0][0] = Ah[0]; fa[0][1] = Al[0];                                                           \
+    fb[0][0] = Bh[pbase[0]]; fb[0][1] = Bl[pbase[0]];                                             \
+    sx_static_for<4>(SX_LAMBDA(s_) { SWP_LOAD_D1(s_, n1_, oy1_) });                               \
+    sx_static_for<20>(SX_LAMBDA(u_) {                                                             \
+      constexpr int u = u_;                                                                       \
+      constexpr int ks = u / 5, t = u % 5;                                                        \
+      constexpr int F = u & 1, FA = ks & 1;                                                       \
+      if constexpr (u < 16 && u % 4 == 0) {                                                       \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(u == 0 ? 16 : 12));                              \
+        SWP_PASS_XS(u / 4)                                                                        \
+      }                                                                                           \
+      bf16x8 bh, bl;                                                                              \
+      if constexpr (t == 4) { bh = shift7(fb[F][0], fb[F][2]); bl = shift7(fb[F][1], fb[F][3]); } \
+      else { bh = fb[F][0]; bl = fb[F][1]; }                                                      \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[FA][0], bl, acc[t], 0, 0, 0);           \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[FA][1], bh, acc[t], 0, 0, 0);           \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[FA][0], bh, acc[t], 0, 0, 0);           \
+      if constexpr (u + 1 < 20) {                                                                 \
+        constexpr int ks1 = (u + 1) / 5, t1 = (u + 1) % 5;                                        \
+        if constexpr (t1 == 0) { fa[ks1 & 1][0] = Ah[2 * ks1]; fa[ks1 & 1][1] = Al[2 * ks1]; }    \
+        fb[F ^ 1][0] = Bh[pbase[t1] + 2 * ks1]; fb[F ^ 1][1] = Bl[pbase[t1] + 2 * ks1];           \
+        if constexpr (t1 == 4) { fb[F ^ 1][2] = Bh[pbase[t1] + 2 * ks1 + 1]; fb[F ^ 1][3] = Bl[pbase[t1] + 2 * ks1 + 1]; } \
+      }                                                                                           \
+      if constexpr (u < 16) { SWP_JOB(0, u / 4, (u % 4) * 2, (PAR) ^ 1) SWP_JOB(0, u / 4, (u % 4) * 2 + 1, (PAR) ^ 1) } \
+      if constexpr (u >= 4) SWP_LOAD_X1(0, (u - 4) / 4, (u - 4) % 4, n2_, oy2_)                   \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    });                                                                                           \
+    __syncthreads();                                                                              \
+    asm volatile("s_waitcnt vmcnt(16)");                                                          \
+    SWP_PASS_D()                                                                                  \
+    SWP_STAGE_D()                                                                                 \
+    __syncthreads();                                                                              \
+    row += 1;                                                                                     \
+  }
+  while (row < last) {
+    SWP_ROW(0)
+    if (row >= last) break;
+    SWP_ROW(1)
+  }
+  asm volatile("s_waitcnt vmcnt(0)");
+  SWP_PASS_X(0) SWP_PASS_D()
+#undef SWP_ROW
+#undef SWP_STAGE_D
+#undef SWP_JOB
+#undef SWP_PASS_D
+#undef SWP_PASS_X
+#undef SWP_PASS_XS
+#undef SWP_LOAD_D1
+#undef SWP_LOAD_X1
+#undef SWP_NOY
+  const int FP = gridDim.y * 64;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int kp = (t < 4 ? ng * 4 + t : 8 + ng) * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c2 = cob * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      a.ws[((size_t)blockIdx.x * FP + c2) * 320 + kp] = acc[t][r];
+    }
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    float v = bpart[s_];
+    v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+    const int c = (s_ * 256 + tid) >> 4;
+    if ((tid & 15) == 0) a.wsb[(size_t)blockIdx.x * FP + cob * 64 + c] = v;
+  }
+}
+
 // dW[f][ci,ky,kx] = sum_b ws[b][f][k'] with k' -> tap decode; db[f] = sum_b wsb[b][f]  (fixed order)
 __global__ void __launch_bounds__(256)
 k_stem_x3_reduce(const float* __restrict__ ws, const float* __restrict__ wsb, int nblk, int F, int FP,
@@ -546,11 +752,17 @@ int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* 
   const int nblk = a.nrows < 256 ? a.nrows : 256;
   a.ws = ws; a.wsb = ws + (size_t)nblk * FP * 320;
   const size_t lds = ((size_t)NPLANE * PE * 2 + 64 * DL * 2) * 2;
-  // Tried and dropped: two bands of prefetch in flight.  With compiler-visible buffer loads (loop unrolled by
-  // two) the time did not move (0.327 ms): the kernel is not latency-bound; with asm loads into reserved
-  // registers hipcc copied the just-loaded tuples before the data landed (tools/audit_asm_loads.py).
-  (void)hipFuncSetAttribute((const void*)k_stem_wgrad_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_stem_wgrad_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
+  const char* e = getenv("FDET_STEM_PIPE");
+  const bool pipe = !(e && e[0] == '0') && a.Wo <= 60 && a.Wo > 48 && (size_t)N * CIN * H * W < ((size_t)1 << 29) &&
+                    (size_t)N * F * a.Ho * a.Wo < ((size_t)1 << 29);
+  if (pipe) {     // pipelined: two plane tiles of 9-chunk planes, exactly four 16-column k-steps (48 < Wo <= 60), 32-bit byte offsets
+    const size_t lds2 = ((size_t)2 * TILEP + 2 * 64 * DL + 8 * PEP) * 2;
+    (void)hipFuncSetAttribute((const void*)k_stem_wgrad_x3_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(k_stem_wgrad_x3_pipe, dim3(nblk, FP / 64), dim3(256), lds2, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)k_stem_wgrad_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_stem_wgrad_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
+  }
   if (int rc = check_launch("fdet_stem_wgrad(bf16x3)")) return rc;
   hipLaunchKernelGGL(k_stem_x3_reduce, dim3(5, F), dim3(256), 0, st, a.ws, a.wsb, nblk, F, FP, dW, db);
   return check_launch("fdet_stem_wgrad(bf16x3 reduce)");

@@ -17,7 +17,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 KERNELS = {
     "fdet_wgrad3x3_x3.hip": ["_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi16E", "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi1ELi0ELi16E",
                              "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi1ELi0ELi32E"],
-    "fdet_stem_x3.hip": ["_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipe"],
+    "fdet_stem_x3.hip": ["_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipe", "_ZN12_GLOBAL__N_120k_stem_wgrad_x3_pipe"],
 }
 
 
