@@ -199,8 +199,10 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     const int it = s * NTHR + tid;
     b_tr[s] = -1; b_xo[s] = 0; b_dst[s] = 0; b_src[s] = -1;
     if (it < 2 * p.p_in) {
-      const int h = it >= p.p_in ? 1 : 0;
-      const int pp = it - h * p.p_in;
+      // k-half fastest: neighbouring lanes write LDS units 3 (mod 8) apart instead of every lane 4 apart --
+      // the 16-byte B stores of a wave fall on twice as many banks (4-way -> 2-way conflicts)
+      const int h = it & 1;
+      const int pp = it >> 1;
       const int tr = fdiv(pp, p.magic_w), ix = (pp - tr * (a.W / VW)) * VW;
       b_tr[s] = tr;
       b_xo[s] = 8 * h * a.H * a.W + ix;
