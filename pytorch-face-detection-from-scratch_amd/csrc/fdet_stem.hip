@@ -152,6 +152,106 @@ k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* _
   if (wid == 0) wsb[(size_t)blockIdx.x * FP + f] = bsum;
 }
 
+// Resnet stem (k3 s2 p1) weight gradient, VALU but scalar-fed: a lane owns one output channel and ALL 27 taps, the
+// eight waves of a workgroup split an output row into chunks of 8 columns.  The x values a chunk needs (3 rows x 17
+// floats per input channel) are the same for every lane: they are read with wave-uniform addresses (scalar loads
+// from the constant cache, no LDS traffic, no staging), so the inner loop is 216 FMAs with a scalar operand per 8
+// LDS reads of dy.  dy rows are staged channel-major in LDS with an odd pitch (lane = channel reads without bank
+// conflicts).  The generic kernel above spends its time on LDS broadcasts of x and on integer divisions in its
+// staging loops (3.9 ms of the 16.6 ms Resnet-640 step); this one takes 1.0 ms.  H, W even; Wo % 4 == 0.
+__global__ void __launch_bounds__(512)
+k_stem_wgrad_k3(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ ws /*[nblk][27][FP]*/,
+                float* __restrict__ wsb /*[nblk][FP]*/, int N, int F, int FP, int H, int W, int Ho, int Wo, int nseg) {
+  // work item = (output row, segment of 64 columns): the eight waves take one 8-column chunk each; the small dy tile
+  // (16.6 KB) lets four workgroups share a CU, whose 32 waves hide the scalar-load latency
+  constexpr int SEG = 64, DS = SEG + 1;
+  __shared__ float D[64 * DS];                          // [64][DS] dy tile; later [8][7][64] wave partials, four rounds
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fb = blockIdx.y;
+  float acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  float bsum = 0.f;
+  const int nitems = N * Ho * nseg;
+  const int ipw = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it0 = blockIdx.x * ipw, it1 = min(it0 + ipw, nitems);
+  const bool w16 = (W % 16 == 0) && ((reinterpret_cast<unsigned long long>(x) & 63) == 0);
+  for (int item = it0; item < it1; ++item) {
+    const int row = item / nseg, seg = item - row * nseg;
+    const int n = row / Ho, oy = row - n * Ho;
+    const int oxs = seg * SEG;
+    __syncthreads();                                    // previous item consumed
+    for (int t = tid; t < 64 * (SEG / 4); t += 512) {
+      const int fl = t >> 4, j = t & 15;
+      const int ff = fb * 64 + fl, ox = oxs + 4 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ff < F && ox < Wo) v = *reinterpret_cast<const float4*>(dy + (((size_t)n * F + ff) * Ho + oy) * Wo + ox);   // Wo % 4 == 0
+      float* d = D + fl * DS + 4 * j;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int ox0 = oxs + wid * 8;
+    if (ox0 < Wo) {
+      const float* Dl = D + lane * DS + wid * 8;
+      float dv[8];
+#pragma unroll
+      for (int o = 0; o < 8; ++o) { dv[o] = Dl[o]; bsum += dv[o]; }            // zeros beyond Wo
+      const bool full = ox0 + 8 <= Wo;                  // wave-uniform
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = 2 * oy + ky - 1;
+          if (iy < 0) continue;                         // top padding row (iy <= H-1 always: H even)
+          const float* xr = x + (((size_t)n * 3 + ci) * H + iy) * W;          // wave-uniform row base
+          float xv[17];                                  // ix = 2*ox0 - 1 + j
+          if (full) {
+            const int b0 = 2 * ox0;                      // multiple of 16 floats: with W % 16 == 0 a 64-byte aligned run
+            xv[0] = ox0 > 0 ? xr[b0 - 1] : 0.f;
+            if (w16) {
+              const float* xa = static_cast<const float*>(__builtin_assume_aligned(xr + b0, 64));
+#pragma unroll
+              for (int j = 0; j < 16; ++j) xv[1 + j] = xa[j];                 // one s_load_dwordx16
+            } else {
+#pragma unroll
+              for (int j = 1; j < 17; ++j) xv[j] = xr[b0 - 1 + j];
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 17; ++j) {
+              const int ix = 2 * ox0 - 1 + j;
+              xv[j] = (ix >= 0 && ix < W) ? xr[ix] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int o = 0; o < 8; ++o) acc[ci * 9 + ky * 3 + kx] = fmaf(dv[o], xv[2 * o + kx], acc[ci * 9 + ky * 3 + kx]);
+        }
+      }
+    }
+  }
+  // combine the eight waves through LDS (the dy tile is free), seven values at a time; one slab per workgroup
+  float* R = D;                                         // [8][7][64]
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 7; ++k) R[(wid * 7 + k) * 64 + lane] = kb * 7 + k < 27 ? acc[kb * 7 + k < 27 ? kb * 7 + k : 0] : bsum;
+    __syncthreads();
+    if (tid < 7 * 64) {
+      const int k = tid >> 6, l = tid & 63;
+      float s_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s_ += R[(w * 7 + k) * 64 + l];
+      const int kk = kb * 7 + k;
+      if (kk < 27) ws[((size_t)blockIdx.x * 27 + kk) * FP + fb * 64 + l] = s_;
+      else wsb[(size_t)blockIdx.x * FP + fb * 64 + l] = s_;
+    }
+  }
+}
+
 // dW[f][k] = sum_b ws[b][k][f] ; db[f] = sum_b wsb[b][f]   (fixed order)
 __global__ void __launch_bounds__(256)
 k_stem_reduce(const float* __restrict__ ws, const float* __restrict__ wsb, int nblk, int KK, int F, int FP,
@@ -197,7 +297,8 @@ bool stem_plan(int N, int Cin, int F, int H, int W, int k, int stride, int pad, 
   p.XS = W + 2 * pad + stride + 4;
   p.DS = p.Wo | 1;
   const int nrows = N * p.Ho;
-  p.nblk = nrows < 512 ? nrows : 512;
+  const int maxblk = k == 3 ? 1024 : 512;               // slabs in the workspace (k3: four workgroups per CU)
+  p.nblk = nrows < maxblk ? nrows : maxblk;
   p.lds_fwd = (size_t)Cin * k * stride * p.BXS * 4;
   p.lds_wg = ((size_t)Cin * k * p.XS + 64 * (size_t)p.DS) * 4;
   p.pack_floats = (size_t)p.KK * p.FP;
@@ -275,6 +376,17 @@ extern "C" int fdet_stem_wgrad(const float* x, const float* dy, float* dW, float
   if (k == 10) {
     if (p.lds_wg > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_stem_wgrad<10, 8, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_wg);
     hipLaunchKernelGGL((k_stem_wgrad<10, 8, 2, 3>), grid, dim3(256), p.lds_wg, st, x, dy, wsW, wsb, N, F, p.FP, H, W, p.Ho, p.Wo, p.XS, p.DS);
+  } else if (H % 2 == 0 && W % 2 == 0 && p.Wo % 4 == 0 && !getenv("FDET_STEM_K3_GENERIC")) {
+    // scalar-fed kernel: items = (row, 64-column segment), four 8-wave workgroups per CU, one slab per workgroup
+    const int nseg = (p.Wo + 63) / 64;
+    const int nitems = N * p.Ho * nseg;
+    int ncu = 256;
+    { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v; }
+    const int nb = std::min(std::min(nitems, 4 * ncu), p.nblk);            // the workspace holds p.nblk slabs
+    hipLaunchKernelGGL(k_stem_wgrad_k3, dim3(nb, p.FP / 64), dim3(512), 0, st, x, dy, wsW, wsb, N, F, p.FP, H, W, p.Ho, p.Wo, nseg);
+    if (int rc = check_launch("fdet_stem_wgrad(k3)")) return rc;
+    hipLaunchKernelGGL(k_stem_reduce, dim3((p.KK * p.FP + p.FP + 255) / 256), dim3(256), 0, st, wsW, wsb, nb, p.KK, F, p.FP, dW, db);
+    return check_launch("fdet_stem_wgrad(reduce)");
   } else {
     if (p.lds_wg > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_stem_wgrad<3, 2, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_wg);
     hipLaunchKernelGGL((k_stem_wgrad<3, 2, 1, 3>), grid, dim3(256), p.lds_wg, st, x, dy, wsW, wsb, N, F, p.FP, H, W, p.Ho, p.Wo, p.XS, p.DS);
