@@ -82,6 +82,16 @@ def infer_bench(model, size, device, frames=100, warm=20):
             det = model(pair, predict=torch.tensor(1))
         torch.cuda.synchronize()
         dt1 = (time.perf_counter() - t0) / frames
+        # the same path replayed from a HIP graph (one graph launch per frame instead of ~20 kernel launches)
+        gp = model.graphed_predict(pair)
+        for _ in range(warm):
+            gp.first(pair)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            det = gp.first(pair)
+        torch.cuda.synchronize()
+        dtg = (time.perf_counter() - t0) / frames
         big = torch.randint(0, 256, (256, 3, size, size), dtype=torch.uint8, generator=g).to(device)
         for _ in range(2):
             model.non_max_suppression(model(model._preprocess(big)))
@@ -94,6 +104,7 @@ def infer_bench(model, size, device, frames=100, warm=20):
         dtb = (time.perf_counter() - t0) / reps
     model.train()
     return {"demo_path_ms_per_frame": round(dt1 * 1e3, 3), "demo_path_fps": round(1.0 / dt1, 1),
+            "demo_path_hipgraph_ms_per_frame": round(dtg * 1e3, 3), "demo_path_hipgraph_fps": round(1.0 / dtg, 1),
             "batched_fps": round(256 / dtb, 1), "batched_ms_per_256": round(dtb * 1e3, 3),
             "what": "uint8 3x480x480 frames -> /255 -> PoolResnet-medium -> decode -> greedy NMS (thresholds 0.5/0.5, "
                     "random-init weights); demo path = 2 stacked frames per call, boxes of image 0 read by the host"}

@@ -83,6 +83,14 @@ class BaseModel(nn.Module):
             return hp.u8_to_f32_norm(x)
         return x.float() / 255.0
 
+    # -------------------------------------------------------------- HIP-graph replay of the demo path
+    def graphed_predict(self, example: torch.Tensor) -> "GraphedPredict":
+        """The launch-bound `forward(frames, predict=1)` path (preprocess -> conv stack -> decode -> NMS: ~20 small
+        launches for two frames) captured ONCE into a HIP graph; each call copies the new frames into the static
+        input, replays the graph and reads the box counts.  Same kernels, same results as `forward(x, predict=1)`;
+        thresholds and weights are those at capture time (re-capture after changing them)."""
+        return GraphedPredict(self, example)
+
     # -------------------------------------------------------------- reference surface
     def summary(self):
         if self.input_shape is None:
@@ -112,3 +120,45 @@ class BaseModel(nn.Module):
         x = self(x)
         bbxs = self.non_max_suppression(x)
         return image, bbxs[0]
+
+
+class GraphedPredict:
+    """See BaseModel.graphed_predict."""
+
+    def __init__(self, model: BaseModel, example: torch.Tensor):
+        if not example.is_cuda:
+            raise hp.N.FdetError("graphed_predict runs on the GPU only: move the example frames to cuda")
+        if model.training:
+            raise hp.N.FdetError("graphed_predict captures the eval path: call model.eval() first")
+        self.model = model
+        self.static_in = example.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(3):                                 # warm-up outside the capture (lazy packs, allocator)
+                self._run()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.rows, self.counts = self._run()
+
+    def _run(self):
+        m = self.model
+        y = m._stack_forward(m._preprocess(self.static_in))
+        return m.reduce_bounding_boxes.forward_batch(y)
+
+    def __call__(self, frames: torch.Tensor = None):
+        """-> tuple of per-image (K_i,5) box tensors [score,x,y,w,h] (views into the static output)."""
+        if frames is not None:
+            self.static_in.copy_(frames, non_blocking=True)
+        self.graph.replay()
+        counts = self.counts.tolist()
+        return tuple(self.rows[i, : counts[i]] if counts[i] else torch.empty(0).reshape(0, 5) for i in range(len(counts)))
+
+    def first(self, frames: torch.Tensor = None):
+        """Boxes of image 0 only, as `forward(x, predict=1)` returns them (models/PoolResnet.py:103-104)."""
+        if frames is not None:
+            self.static_in.copy_(frames, non_blocking=True)
+        self.graph.replay()
+        k = int(self.counts[0])
+        return self.rows[0, :k] if k else torch.empty(0).reshape(0, 5)

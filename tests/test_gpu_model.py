@@ -222,3 +222,22 @@ def test_u8_feeder_matches_direct_path(fd):
             assert torch.equal(x, ref)
             assert torch.equal(y.cpu(), batches[i][1])
             feeder.release(tok)
+
+
+def test_graphed_predict_equals_eager(fd):
+    """HIP-graph replay of the demo path returns exactly what forward(x, predict=1) returns, frame after frame."""
+    from fdet_amd.models.PoolResnet import PoolResnet
+    spec = O.poolresnet_spec(16, (3, 480, 480), 10)
+    P = O.init_params(spec, seed=3)
+    model = PoolResnet(16, (3, 480, 480), 10, probability_threshold=0.45, iou_threshold=0.5)
+    model.load_state_dict({k: v.clone() for k, v in P.items()})
+    model = model.cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    frames = [torch.randint(0, 256, (2, 3, 480, 480), dtype=torch.uint8, generator=g).cuda() for _ in range(3)]
+    gp = model.graphed_predict(frames[0])
+    for f in frames + frames[:1]:
+        eager = model(f, predict=torch.tensor(1))
+        got = gp.first(f)
+        assert got.shape == eager.shape and torch.equal(got.cpu(), eager.cpu())
+        both = gp(f)
+        assert len(both) == 2 and torch.equal(both[0].cpu(), eager.cpu())
