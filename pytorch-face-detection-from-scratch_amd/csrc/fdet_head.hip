@@ -201,23 +201,26 @@ k_head_bwd(const float* __restrict__ x, const float* __restrict__ scale, const f
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_head_reduce(const float* __restrict__ wsW, const float* __restrict__ wsb, int N, int nW, float* __restrict__ dW,
               float* __restrict__ db) {
-  // 64 outputs x 4 image phases per workgroup, fixed-order combine
-  __shared__ float part[256];
+  // 64 outputs x 16 image phases per workgroup (the per-image slabs are 46 KB apart: the sum is a chain of
+  // dependent-latency loads, so more phases = fewer round trips), fixed-order combine
+  __shared__ float part[1024];
   const int q = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + q;
   float s = 0.f;
   if (t < nW) {
-    for (int n = ph; n < N; n += 4) s += wsW[(size_t)n * nW + t];
+    for (int n = ph; n < N; n += 16) s += wsW[(size_t)n * nW + t];
   } else if (t < nW + 5) {
-    for (int n = ph; n < N; n += 4) s += wsb[(size_t)n * 8 + (t - nW)];
+    for (int n = ph; n < N; n += 16) s += wsb[(size_t)n * 8 + (t - nW)];
   }
   part[threadIdx.x] = s;
   __syncthreads();
   if (ph == 0) {
-    const float tot = ((part[q] + part[64 + q]) + part[128 + q]) + part[192 + q];
+    float tot = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) tot += part[p * 64 + q];
     if (t < nW) dW[t] = tot;
     else if (t < nW + 5) db[t - nW] = tot;
   }
@@ -303,6 +306,6 @@ extern "C" int fdet_head_bwd(const float* x, const float* drop_scale, const floa
   }
   if (int rc = check_launch("fdet_head_bwd")) return rc;
   const int nW = 5 * F * kk;
-  hipLaunchKernelGGL(k_head_reduce, dim3((nW + 5 + 63) / 64), dim3(256), 0, st, wsW, wsb, N, nW, dW, db);
+  hipLaunchKernelGGL(k_head_reduce, dim3((nW + 5 + 63) / 64), dim3(1024), 0, st, wsW, wsb, N, nW, dW, db);
   return check_launch("fdet_head_bwd(reduce)");
 }

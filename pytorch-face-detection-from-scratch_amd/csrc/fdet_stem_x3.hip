@@ -687,31 +687,37 @@ k_stem_wgrad_x3_pipe(const StemWgX3Args a) {
 }
 
 // dW[f][ci,ky,kx] = sum_b ws[b][f][k'] with k' -> tap decode; db[f] = sum_b wsb[b][f]  (fixed order)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_stem_x3_reduce(const float* __restrict__ ws, const float* __restrict__ wsb, int nblk, int F, int FP,
                  float* __restrict__ dW, float* __restrict__ db) {
-  __shared__ float part[256];
+  // 64 slab columns x 16 slab phases per workgroup (slabs are 82 KB apart: more phases = fewer dependent round trips)
+  __shared__ float part[1024];
   const int f = blockIdx.y;
   const int kq = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int kp = blockIdx.x * 64 + kq;
   float s = 0.f;
   if (kp < 320)
-    for (int b = ph; b < nblk; b += 4) s += ws[((size_t)b * FP + f) * 320 + kp];
+    for (int b = ph; b < nblk; b += 16) s += ws[((size_t)b * FP + f) * 320 + kp];
   part[threadIdx.x] = s;
   __syncthreads();
   if (ph == 0 && kp < 320) {
     int rr = -1, kx = 0;
     if (kp < 256) { if (kp < NROW * 8) { rr = kp >> 3; kx = (kp & 7) + 2; } }
     else { const int k2 = kp - 256; if (k2 < NROW * 2) { rr = k2 >> 1; kx = k2 & 1; } }
-    if (rr >= 0) dW[((size_t)f * NROW + rr) * KS + kx] = ((part[kq] + part[64 + kq]) + part[128 + kq]) + part[192 + kq];
+    if (rr >= 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) tot += part[p * 64 + kq];
+      dW[((size_t)f * NROW + rr) * KS + kx] = tot;
+    }
   }
   __syncthreads();
   if (blockIdx.x == 0) {
     float t = 0.f;
-    for (int b = threadIdx.x; b < nblk; b += 256) t += wsb[(size_t)b * FP + f];
+    for (int b = threadIdx.x; b < nblk; b += 1024) t += wsb[(size_t)b * FP + f];
     part[threadIdx.x] = t;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = 512; w > 0; w >>= 1) {
       if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
       __syncthreads();
     }
@@ -764,7 +770,7 @@ int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* 
     hipLaunchKernelGGL(k_stem_wgrad_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
   }
   if (int rc = check_launch("fdet_stem_wgrad(bf16x3)")) return rc;
-  hipLaunchKernelGGL(k_stem_x3_reduce, dim3(5, F), dim3(256), 0, st, a.ws, a.wsb, nblk, F, FP, dW, db);
+  hipLaunchKernelGGL(k_stem_x3_reduce, dim3(5, F), dim3(1024), 0, st, a.ws, a.wsb, nblk, F, FP, dW, db);
   return check_launch("fdet_stem_wgrad(bf16x3 reduce)");
 }
 
