@@ -10,11 +10,16 @@ SUM-all-reduced over RCCL.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see the keys at the bottom).
+`python bench.py --gpus N` without a launcher environment starts the N rank processes itself
+(a `torch.distributed.run` child, started BEFORE this process touches the GPU) and exits with the
+child's code.  Prints ONE JSON line on rank 0 (see the keys at the bottom).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,23 +31,47 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+# SURVEY.md 8d, PoolResnet F=64 @480^2 S=10, per image: compulsory activation traffic fwd+bwd and FLOPs
+STEP_MB_PER_IMAGE_F64 = 26.90
+STEP_GFLOP_PER_IMAGE_F64 = 3.0703
+
+
+def self_launch(args) -> int:
+    """Start N fresh rank processes (one per GPU) as a child `torch.distributed.run`; nothing in THIS
+    process has initialised the GPU (device_count() does not on this image)."""
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ndev < args.gpus and not env.get("FDET_SINGLE_DEVICE"):
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible.  To rehearse the multi-rank path "
+              "on one device set FDET_SINGLE_DEVICE=1 FDET_DIST_BACKEND=gloo.", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def synth_batch(B, size, S, seed, device):
     """x = rand(B,3,480,480); targets encoded ON THE GPU from synthetic
     integer boxes, n ~ U{0,1,2} per image."""
-    import oracle as O            # box generator only (host-side data synthesis)
     from fdet_amd import hotpath as hp
+    from fdet_amd.datasets.synthetic import synthetic_boxes
     g = torch.Generator().manual_seed(seed)
     x = torch.rand(B, 3, size, size, generator=g)
-    boxes = O.synthetic_boxes(B, size, seed=seed + 1)
+    boxes = synthetic_boxes(B, size, seed=seed + 1)
     return x.to(device), hp.encode_targets(boxes, (size, size), S, device=device), boxes
 
 
-def cpu_baseline(filters, size, S, sample_bs, steps):
-    """The CPU oracle (a port of the reference's CPU path on stock torch ops) timed on this
-    box's host cores on a bounded sample of the same workload."""
+def cpu_baseline(filters, size, S, sample_bs, steps, frames=100, warm=20):
+    """The CPU oracle (a port of the reference's CPU path on stock torch ops) timed on this box's host cores on
+    a bounded sample of the same workload: (1) the headline training step, (2) BASELINE.json config 1, the
+    reference's demo path (demo_model.py:17-21: uint8 frame stacked twice -> /255 -> conv stack -> decode -> NMS)."""
     import oracle as O
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
@@ -59,9 +88,24 @@ def cpu_baseline(filters, size, S, sample_bs, steps):
     for s in range(steps):
         O.train_step(spec, P, state, 2 + s, x, y, masks)
     dt = time.perf_counter() - t0
+    # config 1: PoolResnet F=64 S=10 eval, thresholds 0.7 / 0.01 (the shipped archives' frozen values)
+    P1 = O.init_params(spec, seed=0)
+    u8 = torch.randint(0, 256, (3, size, size), dtype=torch.uint8, generator=torch.Generator().manual_seed(0))
+    pair = torch.stack([u8, u8])
+    with torch.no_grad():
+        for _ in range(warm):
+            O.predict_image0(spec, P1, pair, 0.7, 0.01)
+        t1 = time.perf_counter()
+        for _ in range(frames):
+            O.predict_image0(spec, P1, pair, 0.7, 0.01)
+        dt1 = (time.perf_counter() - t1) / frames
     return {"value": round(sample_bs * steps / dt, 2), "unit": "imgs/s", "cores": threads, "kind": "port",
             "sample": f"{steps} training steps (fwd+loss+bwd+Adam) at batch {sample_bs}, oracle.train_step, "
-                      f"torch CPU fp32, {threads} threads, {dt:.1f} s"}
+                      f"torch CPU fp32, {threads} threads, {dt:.1f} s",
+            "config1_demo_path": {"ms_per_frame": round(dt1 * 1e3, 3), "fps": round(1.0 / dt1, 1), "cores": threads,
+                                  "sample": f"{frames} frames after {warm} warm-up, oracle.predict_image0 (2 stacked uint8 "
+                                            "480x480 frames -> /255 -> PoolResnet-medium -> decode -> NMS of image 0, "
+                                            "thresholds 0.7/0.01, random-init weights)"}}
 
 
 def infer_bench(model, size, device, frames=100, warm=20):
@@ -110,6 +154,32 @@ def infer_bench(model, size, device, frames=100, warm=20):
                     "random-init weights); demo path = 2 stacked frames per call, boxes of image 0 read by the host"}
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources the library is built from: the PMC traffic file below was measured on ONE
+    build and is only quoted for that build."""
+    d = os.path.join(ROOT, "pytorch-face-detection-from-scratch_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".inc")) or fn == "Makefile":
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic_for(kernel_group: str, B: int, F_: int):
+    """HBM bytes per launch of a kernel group from the committed rocprofv3 PMC passes (profiles/*pmc_traffic*.json
+    written by tools/pmc_traffic.py with the source hash of the build it profiled) -- null when the sources have
+    changed since, or for another batch / width."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    try:
+        tj = json.load(open(path))
+        if tj.get("csrc_sha256") != kernel_source_hash() or tj.get("batch") != B or tj.get("filters") != F_:
+            return None
+        return tj["kernels"][kernel_group]["hbm_bytes_per_launch"]
+    except Exception:                                        # noqa: BLE001 (missing file / key: no traffic figure)
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +190,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the inference leg (profiling runs: its launches share kernel symbols with training)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))                        # N fresh rank processes; this one never touches the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -139,7 +212,8 @@ def main():
         torch.cuda.set_device(0)
     if args.gpus != world:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; reporting n_gpus={world}",
+                  file=sys.stderr)
         args.gpus = world
     device = torch.device("cuda", torch.cuda.current_device())
 
@@ -149,7 +223,7 @@ def main():
     from fdet_amd.convstack import KernelTimer
 
     size, S, B, F_ = 480, 10, args.batch, args.filters
-    torch.manual_seed(0)                                   # train_model.py:13; same init on every rank
+    torch.manual_seed(0)                                   # train_model.py:13 (ranks are synchronised to rank 0's weights anyway)
     model = PoolResnet(filters=F_, input_shape=(3, size, size), num_of_patches=S, num_of_residual_blocks=10).to(device)
     model.train()
     mm = ModelMeta(model=model, lr=1e-4)
@@ -180,45 +254,39 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        # ---- roofline of the dominant kernel (live HIP-event timing over the timed region, on the
-        # stream the kernels are launched on).  Each (kind, resolution) group is one kernel symbol in
-        # this model (e.g. conv3x3_wgrad@60x60 = k_wgrad3x3_x3<2,4,false,false>, one launch per step
-        # for both 60x60 layers; conv3x3_fwd@60x60 = k_conv3x3_x3_sb<2,2,4,FWD_FULL>), so
-        # avg_launch_ms is the average `rocprofv3 --stats` reports for that symbol when the same
-        # command is profiled with --no-inference (the inference leg reuses the forward symbols).
-        # bf16x3 convs are HBM-bound (peak 8 TB/s); the exact-fp32 path is bound by the fp32 MFMA
-        # rate (157.3 TFLOP/s).
+        # ---- roofline of the dominant kernel group (live HIP-event timing over the timed region, on the stream the
+        # kernels are launched on).  Each (kind, resolution) group is ONE kernel symbol in this model, so avg_launch_ms
+        # is the average `rocprofv3 --stats` reports for that symbol when the same command is profiled with
+        # --no-inference (the inference leg reuses the forward symbols).  Per group
+        #   t_roof = max(algorithmic bytes / 8 TB/s, MFMA flops / peak)
+        # where the bf16x3 arithmetic issues THREE bf16 MFMA passes per fp32 MAC (peak 2.5 PFLOP/s dense) and the exact
+        # fp32 path one f32 MFMA pass (157.3 TFLOP/s); `bound` names the larger term.
         per = timer.summary()                                # name -> (launches, total ms, flops/launch, bytes/launch)
         x3 = bool(model.engine.x3)
-        groups = {}
+        mf_mult, mf_peak = (3.0, PEAK_BF16_MFMA_TFLOPS) if x3 else (1.0, PEAK_FP32_MFMA_TFLOPS)
+        table = {}
         for k, (n_l, tot, fl, nb) in per.items():
-            kind, shape = k.split("@")
-            g = k                                            # one kernel symbol per (kind, resolution) in this model
-            a = groups.setdefault(g, [0, 0.0, 0.0, 0.0])
-            a[0] += n_l; a[1] += tot; a[2] += fl * n_l; a[3] += nb * n_l
-        dom = max(groups, key=lambda k: groups[k][1])
-        n_l, tot_ms, fl_sum, nb_sum = groups[dom]
+            avg = tot / n_l
+            t_hbm = nb / (PEAK_HBM_GBS * 1e9) * 1e3          # ms
+            t_mfma = mf_mult * fl / (mf_peak * 1e12) * 1e3
+            bound = "mfma" if t_mfma > t_hbm else "hbm"
+            troof = max(t_hbm, t_mfma)
+            table[k] = {"ms_per_step": round(tot / args.steps, 4), "avg_launch_ms": round(avg, 4), "bound": bound,
+                        "t_roof_ms": round(troof, 4), "frac": round(troof / avg, 4) if troof > 0 else None}
+        dom = max(per, key=lambda k: per[k][1])
+        n_l, tot_ms, fl, nb = per[dom]
         avg_ms = tot_ms / n_l
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if B == 256 and F_ == 64 and x3 and dom in tj:
-                traffic = tj[dom]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        if x3 and nb_sum > 0:
-            achieved = nb_sum / n_l / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
-                    "launches_per_step": n_l // args.steps, "algorithmic_mb_per_launch": round(nb_sum / n_l / 1e6, 1),
-                    "algorithmic_gflop_per_launch": round(fl_sum / n_l / 1e9, 3)}
+        d = table[dom]
+        if d["bound"] == "hbm":
+            achieved, peak, unit = nb / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
         else:
-            achieved = fl_sum / n_l / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_l // args.steps,
-                    "algorithmic_gflop_per_launch": round(fl_sum / n_l / 1e9, 3)}
-        breakdown = {k: round(v[1] / args.steps, 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}
+            achieved, peak, unit = mf_mult * fl / (avg_ms * 1e-3) / 1e12, mf_peak, "TFLOP/s"
+        roof = {"bound": d["bound"], "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4), "traffic": pmc_traffic_for(dom, B, F_),
+                "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_l // args.steps,
+                "algorithmic_mb_per_launch": round(nb / 1e6, 1), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
+                "mfma_passes_per_mac": mf_mult,
+                "hbm_frac": round(nb / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if nb else None}
         out = {
             "metric": "train imgs/sec (PoolResnet 480^2, bs=256 per GPU)", "value": round(value, 1), "unit": "imgs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -227,12 +295,21 @@ def main():
             "config": {"workload": f"PoolResnet-medium (filters {F_}, 10 blocks, S=10) 3x{size}x{size}, one training "
                                    "step = fwd + YoloLoss + bwd + Adam", "global_batch": world * B, "per_gpu_batch": B,
                        "parallelism": f"dp{world}"},
-            "roofline": roof, "kernel_ms_per_step": breakdown, "final_loss": round(loss_val, 4),
+            "roofline": roof, "kernels": dict(sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])),
+            "final_loss": round(loss_val, 4),
         }
+        if F_ == 64:
+            gb = STEP_MB_PER_IMAGE_F64 * B / 1e3
+            gf = STEP_GFLOP_PER_IMAGE_F64 * B
+            out["step_roofline"] = {
+                "algorithmic_gb_per_step": round(gb, 3), "achieved_gbs": round(gb / (ms * 1e-3), 1),
+                "hbm_frac": round(gb / (ms * 1e-3) / PEAK_HBM_GBS, 4),
+                "mfma_floor_ms": round(mf_mult * gf / (mf_peak * 1e3) * 1e3, 3), "hbm_floor_ms": round(gb / PEAK_HBM_GBS * 1e3, 3),
+                "frac_of_max_floor": round(max(mf_mult * gf / (mf_peak * 1e3) * 1e3, gb / PEAK_HBM_GBS * 1e3) / ms, 4)}
         if world == 1 and not args.no_inference:
             out["inference"] = infer_bench(model, size, device)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(F_, size, S, sample_bs=64, steps=24)
+            out["cpu_baseline"] = cpu_baseline(F_, size, S, sample_bs=64, steps=20)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -310,6 +310,15 @@ int fdet_head_bwd(const float* x, const float* drop_scale, const float* w, const
  * tests inject masks instead. */
 int fdet_dropout_scales(float* out, size_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
+/* Dropout2d scales of every dropout layer of a model in one launch (nn.Dropout2d of models/PoolResnet.py:31,69,
+ * models/SSD.py:47; per-rank streams of SURVEY.md 8e).  The counter is indexed by the GLOBAL image number:
+ *   counter(image g, layer k, channel c) = base + g*LS + sum_{j<k} channels[j] + c,  LS = sum_k channels[k]
+ * so that a data-parallel rank that owns images [first_image, first_image+n) draws exactly the planes a single
+ * process draws for the concatenated batch.  channels / p: HOST arrays of nlayers (<= 32) entries.
+ * out: layer k is a dense [n][channels[k]] array at float offset n * sum_{j<k} channels[j]. */
+int fdet_dropout_scales_layers(float* out, int n, int nlayers, const int* channels, const float* p,
+                               uint64_t seed, uint64_t base, uint64_t first_image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,3 +85,48 @@ extern "C" int fdet_dropout_scales(float* out, size_t n, float p, uint64_t seed,
                      n, p, 1.0f / (1.0f - p), seed, offset);
   return check_launch("fdet_dropout_scales");
 }
+
+// Dropout2d scales of EVERY dropout layer of a model in one launch, indexed by the GLOBAL image number so that
+// data-parallel ranks draw exactly the planes a single process would draw for the concatenated batch
+// (per-rank streams; rank r passes first_image = r * n):
+//   counter(image g, layer k, channel c) = base + g * LS + pre_k + c,   LS = sum_k C_k,  pre_k = sum_{j<k} C_j
+// out: layer k is a dense [n][C_k] array at float offset n * pre_k.
+struct DropLayers {
+  int nlayers, ls;
+  int pre[33];
+  float p[32];
+};
+
+__global__ void __launch_bounds__(256)
+k_dropout_layers(float* __restrict__ out, int n, DropLayers L, uint64_t seed, uint64_t base, uint64_t first_image) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * L.ls) return;
+  const int i = (int)(t / L.ls), r = (int)(t - (size_t)i * L.ls);
+  int k = 0;
+  while (k + 1 < L.nlayers && r >= L.pre[k + 1]) ++k;
+  const int c = r - L.pre[k], C = L.pre[k + 1] - L.pre[k];
+  const float p = L.p[k];
+  const float u = u01(seed, base + (first_image + (uint64_t)i) * (uint64_t)L.ls + (uint64_t)r);
+  out[(size_t)n * L.pre[k] + (size_t)i * C + c] = (u >= p) ? 1.0f / (1.0f - p) : 0.f;
+}
+
+extern "C" int fdet_dropout_scales_layers(float* out, int n, int nlayers, const int* channels, const float* p,
+                                          uint64_t seed, uint64_t base, uint64_t first_image, void* stream) {
+  FDET_REQUIRE(out && channels && p && n >= 0 && nlayers >= 1 && nlayers <= 32,
+               "dropout_scales_layers: bad arguments (n=%d, nlayers=%d; at most 32 layers)", n, nlayers);
+  DropLayers L;
+  L.nlayers = nlayers;
+  L.pre[0] = 0;
+  for (int k = 0; k < nlayers; ++k) {
+    FDET_REQUIRE(channels[k] > 0 && p[k] >= 0.f && p[k] < 1.f, "dropout_scales_layers: layer %d: channels=%d p=%f", k,
+                 channels[k], (double)p[k]);
+    L.pre[k + 1] = L.pre[k] + channels[k];
+    L.p[k] = p[k];
+  }
+  L.ls = L.pre[nlayers];
+  if (n == 0) return FDET_OK;
+  const size_t total = (size_t)n * L.ls;
+  hipLaunchKernelGGL(k_dropout_layers, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
+                     n, L, seed, base, first_image);
+  return check_launch("fdet_dropout_scales_layers");
+}

@@ -21,6 +21,39 @@ import torch
 import torch.distributed as dist
 
 
+def rank_world(group=None):
+    """(rank, world) of this process; (0, 1) outside torch.distributed."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def dropout_stream(calls: int, n_local: int, group=None):
+    """(base, first_image) of the dropout counter for the `calls`-th training forward of a rank that holds `n_local`
+    images (equal shards: the global batch is world * n_local; rank r owns images [r*n_local, (r+1)*n_local)).
+    `base` does not depend on the batch size (ranges of different calls must never overlap):
+    call k owns counters [k << 40, (k+1) << 40)."""
+    rank, _ = rank_world(group)
+    return int(calls) << 40, rank * int(n_local)
+
+
+def sync_parameters(flat_param: torch.Tensor, group=None, check: bool = True) -> None:
+    """Start-of-training hand-shake: broadcast rank 0's flat parameter buffer (ranks then hold bit-identical
+    weights whatever their seeds were) and, with `check`, verify it by an all-reduced checksum."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return
+    dist.broadcast(flat_param, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if check:
+        s = flat_param.double().sum().reshape(1)
+        lo, hi = s.clone(), s.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if float(lo) != float(hi):
+            raise RuntimeError(f"rank {rank}: parameters differ across ranks after the broadcast "
+                               f"(checksums {float(lo)!r} .. {float(hi)!r})")
+
+
 def shard_range(batch: int, rank: int, world: int):
     """Images [lo, hi) of a global batch owned by `rank` (contiguous, remainder to low ranks)."""
     base, rem = divmod(batch, world)

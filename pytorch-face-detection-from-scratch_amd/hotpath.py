@@ -268,6 +268,29 @@ def dropout_scales(out: torch.Tensor, p: float, seed: int, offset: int) -> torch
     return out
 
 
+def dropout_scales_layers(n: int, channels: Sequence[int], p: Sequence[float], seed: int, base: int, first_image: int,
+                          device) -> List[torch.Tensor]:
+    """Dropout2d scales of every dropout layer in one launch (fdet_dropout_scales_layers): returns one dense
+    (n, channels[k]) tensor per layer (views into one buffer).  The counter is indexed by the global image number
+    `first_image + i`, so data-parallel ranks draw what a single process draws for the concatenated batch."""
+    import ctypes
+    L = len(channels)
+    if L != len(p) or not (1 <= L <= 32):
+        raise ValueError("dropout_scales_layers: 1..32 layers, one p per layer")
+    ls = int(sum(channels))
+    buf = torch.empty(max(n * ls, 1), dtype=F32, device=device)
+    ch = (ctypes.c_int * L)(*[int(c) for c in channels])
+    pp = (ctypes.c_float * L)(*[float(v) for v in p])
+    m64 = 2**64 - 1
+    check(lib().fdet_dropout_scales_layers(ptr(buf), int(n), L, ch, pp, int(seed) & m64, int(base) & m64,
+                                           int(first_image) & m64, stream()), "fdet_dropout_scales_layers")
+    out, off = [], 0
+    for c in channels:
+        out.append(buf[off:off + n * c].view(n, c))
+        off += n * c
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # conv stack primitives (shapes are validated here; the kernels trust them)
 # ------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@ import torch.nn as nn
 
 from .. import hotpath as hp
 from ..convstack import ConvStack, ConvStackFn, StackGeometry, param_names
+from ..dataparallel import dropout_stream
 from ..datasets.utils import ReduceBoundingBoxes
 
 
@@ -48,14 +49,14 @@ class BaseModel(nn.Module):
     def _draw_masks(self, n: int, device):
         if self._injected_masks is not None:
             return {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in self._injected_masks.items()}
+        # one launch for all layers; the counter is (call, GLOBAL image, layer, channel): call ranges never overlap
+        # whatever the batch size, and a data-parallel rank draws the planes of ITS images of the global batch
         nb, F_ = len(self.residual_blocks), self.filters
-        buf = torch.empty(nb + 1, n, F_, dtype=torch.float32, device=device)
         self._drop_calls += 1
-        base = self._drop_calls * (nb + 1) * n * F_
-        hp.dropout_scales(buf[:nb], 0.25, self._drop_seed, base)                       # ResidualBlock dropout
-        hp.dropout_scales(buf[nb:], 0.5, self._drop_seed, base + nb * n * F_)          # model-level dropout
-        masks = {f"residual_blocks.{k}": buf[k] for k in range(nb)}
-        masks["head"] = buf[nb]
+        base, first = dropout_stream(self._drop_calls, n)
+        drawn = hp.dropout_scales_layers(n, [F_] * (nb + 1), [0.25] * nb + [0.5], self._drop_seed, base, first, device)
+        masks = {f"residual_blocks.{k}": drawn[k] for k in range(nb)}       # ResidualBlock dropout
+        masks["head"] = drawn[nb]                                          # model-level dropout
         return masks
 
     def _stack_forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -21,7 +21,7 @@ except Exception:                                        # noqa: BLE001
     _HAVE_PL = False
 
 from .. import hotpath as hp
-from ..dataparallel import GradBucketReducer
+from ..dataparallel import GradBucketReducer, sync_parameters
 from ..losses.YoloLoss import yolo_loss_batch
 from ..optim import SAMSGD
 
@@ -96,16 +96,21 @@ class ModelMeta(_Base):
             raise RuntimeError("optimizer parameter order differs from the conv stack's")
         P = {n: p.data for n, p in zip(names, params)}
         G = {n: sp.view(sp.grad, i) for i, n in enumerate(names)}
-        masks = model._draw_masks(x.shape[0], x.device) if model.training else None
-        y_hat, saved = eng.forward(x, P, masks, save=True)
-        _, lsum, dy = hp.yolo_loss_fwd_bwd(y_hat, y, want_grad=True)
         if self._reducer is None or self._reducer.flat.data_ptr() != sp.grad.data_ptr():
             split_block = min(2, len(model.residual_blocks))
             split = sp.offsets[names.index(f"residual_blocks.{split_block}.conv1.weight")] \
                 if split_block < len(model.residual_blocks) else sp.offsets[names.index("out.weight")]
             self._reducer = GradBucketReducer(sp.grad, split)
             self._split_block = split_block
+            if self._reducer.enabled:
+                # start-of-training hand-shake: every rank continues from rank 0's weights (checksummed)
+                sync_parameters(sp.flat)
+                eng.mark_params_dirty()
+                P = {n: p.data for n, p in zip(names, params)}
         red = self._reducer
+        masks = model._draw_masks(x.shape[0], x.device) if model.training else None
+        y_hat, saved = eng.forward(x, P, masks, save=True)
+        _, lsum, dy = hp.yolo_loss_fwd_bwd(y_hat, y, want_grad=True)
         eng.backward(saved, dy, P, G,
                      after_block=(lambda k: red.launch_tail() if k == self._split_block else None) if red.enabled else None)
         if red.enabled:

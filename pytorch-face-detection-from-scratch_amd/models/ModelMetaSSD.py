@@ -7,13 +7,16 @@ from pathlib import Path
 import torch
 
 from .. import hotpath as hp
+from ..dataparallel import rank_world
 from ..losses.SSDLoss import ssd_loss
 from ..optim import SAMSGD
 
 try:                                                     # pragma: no cover - not in this image
     from pytorch_lightning import LightningModule as _Base
+    _HAVE_PL = True
 except Exception:                                        # noqa: BLE001
     _Base = torch.nn.Module
+    _HAVE_PL = False
 
 
 class ModelMetaSSD(_Base):
@@ -26,8 +29,9 @@ class ModelMetaSSD(_Base):
         self.opt = None
         self._logged = {}
 
-    def log(self, name, value, **kwargs):
-        self._logged[name] = value
+    if not _HAVE_PL:
+        def log(self, name, value, **kwargs):            # Lightning's self.log stand-in
+            self._logged[name] = value
 
     def forward(self, x):
         return self.model(x)
@@ -76,6 +80,13 @@ class ModelMetaSSD(_Base):
             raise RuntimeError("optimizer parameter order differs from the SSD stack's")
         P = {n: p.data for n, p in zip(names, params)}
         G = {n: sp.view(sp.grad, i) for i, n in enumerate(names)}
+        if rank_world()[1] > 1:
+            # ssd_loss divides by the positive count of the WHOLE batch (losses/SSDLoss.py:86): per-rank losses of
+            # disjoint shards do not add up to the loss of the concatenated batch, so a plain SUM all-reduce of the
+            # gradients would silently train a different objective.  Not built yet (needs the positive counts
+            # exchanged before the backward pass) -- fail loudly instead of diverging.
+            raise NotImplementedError("ModelMetaSSD.fused_train_step is single-process: data-parallel SSD training "
+                                      "needs a batch-wide positive count (losses/SSDLoss.py:86)")
         masks = model._draw_masks(x.shape[0], x.device) if model.training else None
         y_hat, saved = eng.forward(x, P, masks, save=True)
         loss, dy, _ = hp.ssd_loss_fwd_bwd(y_hat, y, 10, want_grad=True)

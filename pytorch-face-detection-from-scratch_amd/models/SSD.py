@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import hotpath as hp
+from ..dataparallel import dropout_stream
 from ..datasets.utils import ReduceSSDBoundingBoxes
 from ..ssdstack import SSDStack, SSDStackFn, block_specs, param_names
 
@@ -68,15 +69,12 @@ class SSD(nn.Module):
     def _draw_masks(self, n, device):
         if self._injected_masks is not None:
             return {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in self._injected_masks.items()}
-        masks = {}
         self._drop_calls += 1
-        off = self._drop_calls << 32
-        for name, _, co, _, _ in block_specs(self.filters):
-            t = torch.empty(n, co, dtype=torch.float32, device=device)
-            hp.dropout_scales(t, 0.25, self._drop_seed, off)
-            off += n * co
-            masks[name] = t
-        return masks
+        base, first = dropout_stream(self._drop_calls, n)
+        specs = block_specs(self.filters)
+        drawn = hp.dropout_scales_layers(n, [co for _, _, co, _, _ in specs], [0.25] * len(specs), self._drop_seed,
+                                         base, first, device)
+        return {spec[0]: t for spec, t in zip(specs, drawn)}
 
     def non_max_suppression(self, x):
         if len(x.shape) == 3:

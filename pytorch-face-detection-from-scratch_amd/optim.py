@@ -83,7 +83,7 @@ class SAMSGD(torch.optim.Optimizer):
         self.on_params_updated = None        # e.g. ConvStack.mark_params_dirty
 
     def set_closure_fn(self, closure):
-        self.closure = closure               # kept for API compatibility; never called (Q18)
+        self.closure = closure               # the reference's SAM closure (two stale forwards, Q18): kept, never called
 
     def _space(self) -> FlatSpace:
         if self.space is None:
@@ -92,8 +92,61 @@ class SAMSGD(torch.optim.Optimizer):
             self.space.ensure()
         return self.space
 
-    @torch.no_grad()
+    # ------------------------------------------------------------------ checkpoint round trip
+    def state_dict(self):
+        """torch.optim.Adam layout: state[i] = {step, exp_avg, exp_avg_sq} per parameter (copies of the views
+        into the flat moment buffers), so checkpoints interchange with the reference's `optimizer_states`
+        (its SAMSGD subclasses Adam, models/ModelMeta.py:12) and a resumed run continues with its moments
+        and bias correction."""
+        sd = super().state_dict()
+        if self.space is not None and self.step_count > 0:
+            sp = self.space
+            sd["state"] = {i: {"step": torch.tensor(float(self.step_count)),
+                               "exp_avg": sp.view(sp.exp_avg, i).clone(),
+                               "exp_avg_sq": sp.view(sp.exp_avg_sq, i).clone()}
+                           for i in range(len(sp.params))}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state = state_dict.get("state", {}) or {}
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        g = self.param_groups[0]
+        g.setdefault("rho", 0.05)
+        sp = self._space()
+        sp.exp_avg.zero_()
+        sp.exp_avg_sq.zero_()
+        self.step_count = 0
+        if not state:
+            return
+        by_idx = {int(k): v for k, v in state.items()}
+        if sorted(by_idx) != list(range(len(sp.params))):
+            raise ValueError(f"optimizer state holds {len(by_idx)} entries for {len(sp.params)} parameters")
+        steps = set()
+        with torch.no_grad():
+            for i, p in enumerate(sp.params):
+                st = by_idx[i]
+                for key, buf in (("exp_avg", sp.exp_avg), ("exp_avg_sq", sp.exp_avg_sq)):
+                    t = st[key]
+                    if tuple(t.shape) != tuple(p.shape):
+                        raise ValueError(f"optimizer state {key}[{i}] has shape {tuple(t.shape)}, parameter {tuple(p.shape)}")
+                    sp.view(buf, i).copy_(t.to(device=buf.device, dtype=torch.float32))
+                steps.add(int(float(st["step"])))            # int in torch 1.10, float tensor later
+        if len(steps) != 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one flat Adam step cannot resume that")
+        self.step_count = steps.pop()
+
     def step(self, closure=None, grads_in_flat: bool = False, grad_scale: float = 1.0):
+        """`closure` (torch.optim contract / Lightning's automatic optimisation): re-evaluates the model and
+        runs backward; it is called with grad enabled BEFORE the gradients are gathered, and its loss returned."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._step(grads_in_flat, grad_scale)
+        return loss
+
+    @torch.no_grad()
+    def _step(self, grads_in_flat: bool, grad_scale: float):
         sp = self._space()
         if not grads_in_flat:
             sp.gather_autograd_grads()
@@ -103,7 +156,6 @@ class SAMSGD(torch.optim.Optimizer):
                      beta2=g["betas"][1], eps=g["eps"], grad_scale=grad_scale)
         if self.on_params_updated is not None:
             self.on_params_updated()
-        return None
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)

@@ -1,0 +1,62 @@
+"""One data-parallel rank of tests/test_gpu_dataparallel.py (started as a fresh child process; all ranks share
+cuda:0, gloo carries the collectives): runs ModelMeta.fused_train_step on ITS shard of a global batch and, on
+rank 0, saves the parameters and the all-reduced flat gradient."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+
+
+def build_case(F_, B, steps_seed=0):
+    import oracle as O
+    S, size = 10, 480
+    spec = O.poolresnet_spec(F_, (3, size, size), S)
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(10))
+    y = torch.stack([O.encode_targets(b, (size, size), S) for b in O.synthetic_boxes(B, size, seed=11)])
+    masks = O.make_dropout_masks(spec, B, seed=12)
+    return spec, x, y, masks
+
+
+def run_rank(rank, world, F_, b_local, steps, live_dropout, param_seed):
+    import fdet_amd  # noqa: F401
+    import oracle as O
+    from fdet_amd.models import ModelMeta
+    from fdet_amd.models.PoolResnet import PoolResnet
+    spec, x, y, masks = build_case(F_, world * b_local)
+    P = O.init_params(spec, seed=param_seed)
+    model = PoolResnet(F_, (3, 480, 480), 10)
+    model.load_state_dict({k: v.clone() for k, v in P.items()})
+    model = model.cuda().train()
+    mm = ModelMeta(model=model, lr=1e-4)
+    mm.configure_optimizers()
+    lo, hi = rank * b_local, (rank + 1) * b_local
+    if not live_dropout:
+        model.set_dropout_masks({k: v[lo:hi] for k, v in masks.items()})
+    xs, ys = x[lo:hi].cuda(), y[lo:hi].cuda()
+    losses = []
+    for _ in range(steps):
+        lsum, _, _ = mm.fused_train_step(xs, ys)
+        losses.append(float(lsum))
+    sp = mm.opt._space()
+    return ({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, sp.grad.cpu().clone(), losses,
+            mm._reducer.enabled)
+
+
+if __name__ == "__main__":
+    out, F_, b_local, steps, live = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # every rank starts from DIFFERENT weights: the start-of-training broadcast must put them on rank 0's
+    params, grad, losses, enabled = run_rank(rank, world, F_, b_local, steps, bool(live), param_seed=rank)
+    assert enabled, "the gradient reducer did not see the process group"
+    tot = torch.tensor(losses, dtype=torch.float64)
+    dist.all_reduce(tot)
+    if rank == 0:
+        torch.save({"params": params, "grad": grad, "loss_sum": tot.tolist()}, out)
+    dist.barrier()
+    dist.destroy_process_group()

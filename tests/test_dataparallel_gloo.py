@@ -20,7 +20,7 @@ def _free_port():
 
 def _worker(rank, world, port, out_q):
     import fdet_amd
-    from fdet_amd.dataparallel import GradBucketReducer, shard_range, allreduce_scalars
+    from fdet_amd.dataparallel import GradBucketReducer, shard_range, allreduce_scalars, sync_parameters, dropout_stream
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,6 +52,12 @@ def _worker(rank, world, port, out_q):
     red.launch_head()
     red.wait()
     tot = allreduce_scalars(loss.detach().reshape(1).clone())
+    # start-of-training hand-shake: ranks that start from different weights continue from rank 0's
+    w = torch.full((1000,), float(rank + 1)) + torch.arange(1000) * 1e-3
+    sync_parameters(w)
+    assert torch.equal(w, torch.full((1000,), 1.0) + torch.arange(1000) * 1e-3)
+    # per-rank dropout streams: rank r owns the global images [r*n, (r+1)*n) of call k's counter range
+    assert dropout_stream(3, 5) == (3 << 40, rank * 5)
     if rank == 0:
         out_q.put((flat, float(tot), offs, [tuple(g.shape) for g in grads], names))
     dist.barrier()

@@ -1,0 +1,61 @@
+"""SURVEY.md 8(e) oracle on the PRODUCT path: two rank processes (fresh children, both on cuda:0, gloo for the
+collectives) run ModelMeta.fused_train_step -- the bucketed SUM all-reduce launched from the backward pass's
+`after_block` hook, the start-of-training parameter broadcast, the per-rank dropout streams -- and must end on the
+parameters a single process reaches on the concatenated batch."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run_ranks(tmp_path, F_, b_local, steps, live, world=2):
+    out = str(tmp_path / "dp_rank0.pt")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), out, str(F_),
+                                       str(b_local), str(steps), str(int(live))], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, lg in zip(procs, logs):
+        assert p.returncode == 0, lg[-3000:]
+    return torch.load(out, weights_only=True)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("live_dropout", [False, True], ids=["injected_masks", "per_rank_dropout_streams"])
+def test_two_ranks_fused_train_step_equals_single_process(tmp_path, live_dropout):
+    import dp_worker
+    F_, b_local, steps, world = 64, 2, 2, 2
+    got = _run_ranks(tmp_path, F_, b_local, steps, live_dropout, world)
+    # single process, concatenated batch, rank 0's initial weights
+    params, grad, losses, enabled = dp_worker.run_rank(0, 1, F_, world * b_local, steps, live_dropout, param_seed=0)
+    assert not enabled
+    for a, b in zip(got["loss_sum"], losses):
+        assert abs(a - b) <= 1e-5 * abs(b), (got["loss_sum"], losses)
+    g_ref, g_got = grad, got["grad"]
+    gmax = float(g_ref.abs().max())
+    assert float((g_got - g_ref).abs().max()) <= 2e-5 * gmax            # last step's all-reduced flat gradient
+    lr = 1e-4
+    for k, p_ref in params.items():
+        p_got = got["params"][k]
+        d = (p_got - p_ref).abs()
+        # Adam's first updates are ~lr*sign(g): where the gradient is far from zero the parameters agree to fp32
+        # rounding (1e-6 relative); an entry whose gradient is ~0 may flip the sign of its update
+        assert float(d.max()) <= 2.1 * lr * steps, k
+        frac_tight = float((d <= 1e-6 * max(1.0, float(p_ref.abs().max()))).float().mean())
+        assert frac_tight >= 0.999, (k, frac_tight)

@@ -84,3 +84,97 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), os.path.join(dp, f)
+
+
+def test_optimizer_state_dict_round_trip_in_adam_layout():
+    """SAMSGD exports / loads its flat Adam moments in torch.optim.Adam's per-parameter layout, so a
+    resumed run keeps its moments and bias-correction step, and the reference's `optimizer_states` load."""
+    import fdet_amd  # noqa: F401
+    from fdet_amd.optim import SAMSGD
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2, 3, 3))]
+    opt = SAMSGD(ps, lr=1e-3)
+    sp = opt._space()
+    sp.exp_avg.uniform_(-1, 1); sp.exp_avg_sq.uniform_(0, 1); opt.step_count = 7
+    sd = opt.state_dict()
+    assert sorted(sd["state"]) == [0, 1, 2] and float(sd["state"][1]["step"]) == 7.0
+    for i, p in enumerate(ps):
+        assert sd["state"][i]["exp_avg"].shape == p.shape
+    # (1) into a fresh SAMSGD
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = SAMSGD(ps2, lr=5e-2)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 7 and opt2.param_groups[0]["lr"] == 1e-3
+    for i in range(3):
+        assert torch.equal(opt2.space.view(opt2.space.exp_avg, i), sp.view(sp.exp_avg, i))
+        assert torch.equal(opt2.space.view(opt2.space.exp_avg_sq, i), sp.view(sp.exp_avg_sq, i))
+    # (2) torch.optim.Adam reads the same dict (the reference's SAMSGD IS an Adam subclass) ...
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-3)
+    ref.load_state_dict({"state": sd["state"], "param_groups": ref.state_dict()["param_groups"]})
+    rp = ref.param_groups[0]["params"]
+    assert torch.equal(ref.state[rp[2]]["exp_avg_sq"], sp.view(sp.exp_avg_sq, 2))
+    # ... and a stock Adam checkpoint loads into SAMSGD
+    for p in rp:
+        p.grad = torch.randn_like(p)
+    ref.step()
+    opt3 = SAMSGD([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-3)
+    opt3.load_state_dict(ref.state_dict())
+    assert opt3.step_count == 8
+    assert torch.equal(opt3.space.view(opt3.space.exp_avg, 0), ref.state[rp[0]]["exp_avg"])
+    # before the first step there is no state to export, as torch's optimizers
+    assert SAMSGD([torch.nn.Parameter(torch.zeros(3))], lr=1e-3).state_dict()["state"] == {}
+
+
+def test_optimizer_step_calls_the_closure_with_grad_enabled():
+    import fdet_amd  # noqa: F401
+    from fdet_amd.optim import SAMSGD
+    p = torch.nn.Parameter(torch.ones(4))
+    opt = SAMSGD([p], lr=1e-3)
+    seen = {}
+
+    def closure():
+        seen["grad_enabled"] = torch.is_grad_enabled()
+        loss = (p * 2).sum()
+        loss.backward()
+        return loss
+
+    opt._step = lambda *a, **k: seen.setdefault("stepped", p.grad is not None)      # no GPU here: stub the launch
+    with torch.no_grad():
+        out = opt.step(closure)
+    assert seen == {"grad_enabled": True, "stepped": True} and float(out) == 8.0
+
+
+def test_dropout_call_ranges_are_disjoint_for_any_batch_size():
+    """the counter base of call k must not depend on the batch size."""
+    import fdet_amd  # noqa: F401
+    from fdet_amd.dataparallel import dropout_stream
+    spans = []
+    for calls, n in ((1, 256), (2, 3), (3, 1024), (4, 1)):
+        base, first = dropout_stream(calls, n)
+        assert first == 0
+        spans.append((base, base + (first + n) * 11 * 64))
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0
+
+
+def test_package_synthetic_boxes_equal_the_oracles():
+    import fdet_amd  # noqa: F401
+    import oracle as O
+    from fdet_amd.datasets.synthetic import synthetic_boxes
+    for a, b in zip(synthetic_boxes(16, 480, seed=101), O.synthetic_boxes(16, 480, seed=101)):
+        assert torch.equal(a, b)
+
+
+def test_bench_self_launch_refuses_more_ranks_than_gpus_without_touching_one():
+    """`bench.py --gpus 2` with no launcher environment starts rank processes itself; on a box with fewer GPUs it
+    says so (exit 2) instead of silently running one rank and printing n_gpus: 1 (VERDICT r1 weak #8a)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FDET_SINGLE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2 and "GPU(s) are visible" in r.stderr and r.stdout.strip() == ""
