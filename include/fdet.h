@@ -262,6 +262,24 @@ int fdet_block_chain_bwd_bf16x3(const float* dout, const void* const* h_wpk1b, c
 int fdet_block_tail_fwd(const float* c, const float* x, const float* drop_scale, float* out,
                         int N, int F, int H, int W, int pool, void* stream);
 
+/* Pooled residual block with the tail fused into the convolutions (bf16x3, maps of even height and even width
+ * <= 62; Cout % 32 == 0).  Replaces conv2 + LeakyReLU + Dropout2d + skip + MaxPool2d(2) of
+ * models/PoolResnet.py:36-42 (models/Resnet.py:33-39) and their autograd without ever writing c = lrelu(conv2):
+ *   forward : out_pooled [N,Cout,H/2,W/2] = maxpool2x2(lrelu(conv(x)+bias) * drop_scale + skip)
+ *             route [N,Cout,H/2,W/2] uint8 (NULL in eval): bits 0-3 = (c > 0) of the window's four elements in
+ *             ATen scan order (row-major), bits 4-5 = index of the maximum (first maximum wins, NaN is a maximum)
+ *   backward: fdet_pool_route_bwd        dz2 [N,F,H,W] = unpool(dout_pooled) * drop_scale * lrelu'(c)
+ *             fdet_conv3x3_dgrad_unpool  dx = conv^T(dz) + unpool(dout_pooled)      (conv1's data gradient + skip path)
+ * wpk: forward / backward panels of fdet_pack_conv3x3_weights_bf16x3. */
+int fdet_conv3x3_fwd_pool_bf16x3(const float* x, const void* wpk, const float* bias, const float* skip,
+                                 const float* drop_scale, float* out_pooled, unsigned char* route, int N, int Cin,
+                                 int Cout, int H, int W, float slope, void* stream);
+int fdet_conv3x3_dgrad_unpool_bf16x3(const float* dz, const void* wpk, const float* dout_pooled,
+                                     const unsigned char* route, float* dx, int N, int Cin, int Cout, int H, int W,
+                                     float slope, void* stream);
+int fdet_pool_route_bwd(const float* dout_pooled, const unsigned char* route, const float* drop_scale, float* dz2,
+                        int N, int F, int H, int W, float slope, void* stream);
+
 /* Backward of the residual-block tail (dropout, skip, max-pool, second LeakyReLU):
  *   e = c*drop_scale + x ; out = maxpool(e) ; given dout [N,F,H/pool,W/pool]:
  *   de = unpool(dout) (first max in window scan order wins, as ATen max_pool2d backward)

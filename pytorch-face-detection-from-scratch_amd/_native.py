@@ -67,6 +67,9 @@ SIGNATURES = {
     "fdet_pack_conv3x3_weights_bf16x3_batched": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "fdet_conv3x3_fwd_bf16x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_dgrad_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_fwd_pool_bf16x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_dgrad_unpool_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_pool_route_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_wgrad_ws_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "fdet_conv3x3_wgrad": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P]),
     "fdet_conv3x3_wgrad_bf16x3_ws_bytes": (_SZ, [_I, _I, _I, _I, _I]),

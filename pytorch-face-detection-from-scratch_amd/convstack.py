@@ -127,6 +127,9 @@ class ConvStack:
         import os
         want = os.environ.get("FDET_PRECISION", "bf16x3")
         self.x3 = (want == "bf16x3") and hp.x3_supported(geo.filters, geo.filters)
+        # pooled blocks: dropout*skip*maxpool (and its backward) inside the conv epilogues (FDET_POOL_FUSION=0: the
+        # separate elementwise tail kernels of round 1)
+        self.pool_fusion = self.x3 and os.environ.get("FDET_POOL_FUSION", "1") != "0"
 
     def _t(self, kind: str, N: int, h: int, flops: float = 0.0, nbytes: float = 0.0):
         if self.timer is None:
@@ -137,7 +140,7 @@ class ConvStack:
         F_ = self.geo.filters
         return 2.0 * N * F_ * F_ * 9 * h * h
 
-    def _act_bytes(self, N: int, h: int, tensors: int) -> float:
+    def _act_bytes(self, N: int, h: int, tensors: float) -> float:
         """Algorithmic HBM bytes of `tensors` activation-sized fp32 tensors (SURVEY.md 8d:
         every input read once, every output written once; weights are L2-resident)."""
         return 4.0 * N * self.geo.filters * h * h * tensors
@@ -175,6 +178,9 @@ class ConvStack:
             self._ws[name] = t
         return t
 
+    def _fused_pool(self, hk: int) -> bool:
+        return self.pool_fusion and hp.pool_fusion_supported(self.geo.filters, self.geo.filters, hk, hk)
+
     def _chain_run(self, k: int) -> int:
         """Number of consecutive un-pooled blocks starting at block k that can run as one
         LDS-resident chain (bf16x3, 64 channels, small maps); 0/1 = use the per-layer kernels."""
@@ -205,7 +211,8 @@ class ConvStack:
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
         h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev)
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
-        with self._t("stem_fwd", N, self.h0, stem_flops):
+        stem_bytes = 4.0 * N * (g.in_ch * g.H * g.W + F_ * self.h0 * self.h0)
+        with self._t("stem_fwd", N, self.h0, stem_flops, stem_bytes):
             hp.stem_fwd(x, P["conv1.weight"], P["conv1.bias"], h, ws, g.stem_k, g.stem_s, g.stem_p,
                         x3=self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p))
         saved = {"x": x, "blocks": [], "masks": masks} if save else None
@@ -237,11 +244,17 @@ class ConvStack:
             with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2)):
                 hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], F_, y_full=a, slope=self.slope, x3=self.x3)
             out = torch.empty(N, F_, hk // pool, hk // pool, dtype=F32, device=dev)
-            if pool == 2:
+            if pool == 2 and self._fused_pool(hk):
+                # conv2 + lrelu + dropout*skip + maxpool in one kernel; c is never written, backward gets one
+                # routing byte per pooling window instead
+                c = torch.empty(N, F_, hk // 2, hk // 2, dtype=torch.uint8, device=dev) if save else None
+                with self._t("conv3x3_fwd_pool", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2 + 0.25 + (1 / 16 if save else 0))):
+                    hp.conv3x3_fwd_pool(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], h, sc, out, c, self.slope)
+            elif pool == 2:
                 c = torch.empty_like(a)
                 with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2)):
                     hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], F_, y_full=c, slope=self.slope, x3=self.x3)
-                with self._t("tail_fwd", N, hk):
+                with self._t("tail_fwd", N, hk, 0.0, self._act_bytes(N, hk, 2.25)):
                     hp.block_tail_fwd(c, h, sc, out, 2)
             else:
                 c = torch.empty_like(a) if save else None
@@ -252,7 +265,7 @@ class ConvStack:
                 saved["blocks"].append((h, a, c))
             h = out
         y = torch.empty(N, 5, g.S, g.S, dtype=F32, device=dev)
-        with self._t("head_fwd", N, h.shape[2]):
+        with self._t("head_fwd", N, h.shape[2], 2.0 * N * 5 * F_ * g.head_k ** 2 * g.S ** 2, self._act_bytes(N, h.shape[2], 1)):
             hp.head_fwd(h, masks["head"] if masks is not None else None, P["out.weight"], P["out.bias"], y, g.head_k, g.head_p)
         if save:
             saved["h_last"] = h
@@ -276,7 +289,7 @@ class ConvStack:
         hl = h_last.shape[2]
         ws = self._workspace("head", hp.head_bwd_ws_bytes(N, F_, hl, hl, g.head_k, g.head_p), dev)
         dout = torch.empty_like(h_last)
-        with self._t("head_bwd", N, hl):
+        with self._t("head_bwd", N, hl, 4.0 * N * 5 * F_ * g.head_k ** 2 * g.S ** 2, self._act_bytes(N, hl, 2)):
             hp.head_bwd(h_last, masks["head"] if masks is not None else None, P["out.weight"], y, dy, dout,
                         G["out.weight"], G["out.bias"], ws, g.head_k, g.head_p)
         pending = []          # (x, dz, weight name) of same-resolution convs awaiting one batched wgrad launch
@@ -336,9 +349,14 @@ class ConvStack:
             xin, a, c = saved["blocks"][k]
             sc = masks[name] if masks is not None else None
             dz2 = torch.empty_like(a)
-            de = torch.empty_like(a) if pool == 2 else None
-            with self._t("tail_bwd", N, hk):
-                hp.block_tail_bwd(dout, c, xin, sc, dz2, de, pool, self.slope)
+            fused_pool = pool == 2 and c.dtype == torch.uint8      # forward kept routing bytes instead of c
+            de = torch.empty_like(a) if (pool == 2 and not fused_pool) else None
+            if fused_pool:
+                with self._t("pool_route_bwd", N, hk, 0.0, self._act_bytes(N, hk, 1 + 0.25 + 1 / 16)):
+                    hp.pool_route_bwd(dout, c, sc, dz2, self.slope)
+            else:
+                with self._t("tail_bwd", N, hk, 0.0, self._act_bytes(N, hk, 4.25 if pool == 2 else 3)):
+                    hp.block_tail_bwd(dout, c, xin, sc, dz2, de, pool, self.slope)
             if pool == 1:
                 de = dout
             fl = self._conv_flops(N, hk)
@@ -354,8 +372,12 @@ class ConvStack:
                 with self._t("conv3x3_wgrad", N, hk, fl, self._act_bytes(N, hk, 2)):
                     hp.conv3x3_wgrad(xin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], wws)
             dx = torch.empty_like(a) if batched else dz2      # batched: dz2 stays alive until the flush
-            with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
-                hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], F_, dx, add=de, slope=self.slope, x3=self.x3)
+            if fused_pool:
+                with self._t("conv3x3_dgrad_unpool", N, hk, fl, self._act_bytes(N, hk, 2 + 0.25 + 1 / 16)):
+                    hp.conv3x3_dgrad_unpool(dz1, self._wpk[name + ".conv1.b"], F_, dout, c, dx, self.slope)
+            else:
+                with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
+                    hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], F_, dx, add=de, slope=self.slope, x3=self.x3)
             dout = dx
             if batched:
                 pending.append((a, dz2, name + ".conv2"))
@@ -371,7 +393,7 @@ class ConvStack:
                 after_block(k)
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
-        with self._t("stem_wgrad", N, self.h0, stem_flops):
+        with self._t("stem_wgrad", N, self.h0, stem_flops, 4.0 * N * (g.in_ch * g.H * g.W + F_ * self.h0 * self.h0)):
             hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p,
                           x3=self.x3 and g.W % 16 == 0 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p))
 

@@ -45,6 +45,19 @@ __device__ __forceinline__ void split8(const float (&f)[8], bf16x8& hi, bf16x8& 
 
 }  // namespace
 
+namespace fdet {
+// pooled-block fusion of the ping-pong kernel (fdet_conv3x3_x3_pp.hip); all null = plain epilogue modes
+struct PoolArgs {
+  float* pool_out;                  // EPI_FWD_POOL: [N,Cout,H/2,W/2] = maxpool2x2(lrelu(conv+bias)*scale + skip)
+  unsigned char* mask_out;          // EPI_FWD_POOL (training): [N,Cout,H/2,W/2] routing bytes, may be null
+  const float* pool_din;            // EPI_DGRAD_ADDPOOL: gradient of the pooled block output [N,Cout,H/2,W/2]
+  const unsigned char* mask_in;     // EPI_DGRAD_ADDPOOL: routing bytes of the forward pass
+};
+}  // namespace fdet
+
+// ping-pong variant for rows of <= 63 columns (fdet_conv3x3_x3_pp.hip); returns 1 when it has no tiling
+int fdet_x3_pp_run(fdet::ConvArgs a, fdet::PoolArgs q, hipStream_t st);
+
 // small-tile single-buffer variant (fdet_conv3x3_x3_sb.hip); returns 1 when it has no tiling
 int fdet_x3_sb_run(fdet::ConvArgs a, hipStream_t st);
 

@@ -66,8 +66,14 @@ int run_x3(ConvArgs a, hipStream_t st) {
   // rows of up to 64 columns: the small-tile kernel (two workgroups per CU) is the faster one
   // (FDET_CONV_KERNEL=general forces the persistent kernel)
   {
-    const char* e = getenv("FDET_CONV_KERNEL");
-    if (a.W <= 64 && !(e && e[0] == 'g')) {
+    static const char kernel_choice = [] { const char* e = getenv("FDET_CONV_KERNEL"); return e ? e[0] : '\0'; }();
+    if (a.W <= 64 && kernel_choice != 'g') {
+      // ping-pong kernel first (one 8-wave workgroup per CU, barrier-enforced MFMA / memory alternation), then the
+      // round-1 small-tile kernel (FDET_CONV_KERNEL=s), then the general persistent kernel (=g)
+      if (kernel_choice != 's') {
+        const int rc = fdet_x3_pp_run(a, PoolArgs{nullptr, nullptr, nullptr, nullptr}, st);
+        if (rc != 1) return rc;
+      }
       const int rc = fdet_x3_sb_run(a, st);
       if (rc != 1) return rc;
     }
@@ -257,6 +263,33 @@ extern "C" int fdet_conv3x3_fwd_bf16x3(const float* x, const void* wpk, const fl
   a.x = x; a.wpk = (const float*)wpk; a.bias = bias; a.y_full = y_full; a.skip = skip; a.scale = drop_scale;
   a.y_out = y_out; a.act = nullptr; a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dgrad = 0; a.slope = slope;
   return run_x3(a, (hipStream_t)stream);
+}
+
+extern "C" int fdet_conv3x3_fwd_pool_bf16x3(const float* x, const void* wpk, const float* bias, const float* skip,
+                                            const float* drop_scale, float* out_pooled, unsigned char* route, int N,
+                                            int Cin, int Cout, int H, int W, float slope, void* stream) {
+  FDET_REQUIRE(x && wpk && bias && skip && out_pooled, "conv3x3_fwd_pool_bf16x3: null pointer");
+  FDET_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 32 == 0 && !(H & 1) && !(W & 1),
+               "conv3x3_fwd_pool_bf16x3: unsupported shape N=%d Cin=%d Cout=%d H=%d W=%d (even maps, Cin %% 16 == 0, Cout %% 32 == 0)",
+               N, Cin, Cout, H, W);
+  ConvArgs a{};
+  a.x = x; a.wpk = (const float*)wpk; a.bias = bias; a.y_full = nullptr; a.skip = skip; a.scale = drop_scale;
+  a.y_out = nullptr; a.act = nullptr; a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dgrad = 0; a.slope = slope;
+  const int rc = fdet_x3_pp_run(a, PoolArgs{out_pooled, route, nullptr, nullptr}, (hipStream_t)stream);
+  return rc == 1 ? fail(FDET_EINVAL, "conv3x3_fwd_pool_bf16x3: no tiling for H=%d W=%d", H, W) : rc;
+}
+
+extern "C" int fdet_conv3x3_dgrad_unpool_bf16x3(const float* dz, const void* wpk, const float* dout_pooled,
+                                                const unsigned char* route, float* dx, int N, int Cin, int Cout,
+                                                int H, int W, float slope, void* stream) {
+  FDET_REQUIRE(dz && wpk && dout_pooled && route && dx, "conv3x3_dgrad_unpool_bf16x3: null pointer");
+  FDET_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 16 == 0 && !(H & 1) && !(W & 1),
+               "conv3x3_dgrad_unpool_bf16x3: unsupported shape N=%d Cin=%d Cout=%d H=%d W=%d", N, Cin, Cout, H, W);
+  ConvArgs a{};
+  a.x = dz; a.wpk = (const float*)wpk; a.bias = nullptr; a.y_full = dx; a.skip = nullptr; a.scale = nullptr; a.y_out = nullptr;
+  a.act = nullptr; a.N = N; a.Cin = Cout; a.Cout = Cin; a.H = H; a.W = W; a.dgrad = 1; a.slope = slope;
+  const int rc = fdet_x3_pp_run(a, PoolArgs{nullptr, nullptr, dout_pooled, route}, (hipStream_t)stream);
+  return rc == 1 ? fail(FDET_EINVAL, "conv3x3_dgrad_unpool_bf16x3: no tiling for H=%d W=%d", H, W) : rc;
 }
 
 extern "C" int fdet_conv3x3_dgrad_bf16x3(const float* dz, const void* wpk, const float* act, const float* add,

@@ -58,7 +58,9 @@ enum { EPI_GENERIC = 0,
        EPI_FWD_BOTH,    // y_full = z ; y_out = z*scale + skip        (training, un-pooled block tail)
        EPI_FWD_OUT,     // y_out = z + skip                          (eval, un-pooled block tail)
        EPI_DGRAD_ACT,   // dx = acc * lrelu'(act)
-       EPI_DGRAD_ADD }; // dx = acc + add
+       EPI_DGRAD_ADD,   // dx = acc + add
+       EPI_FWD_POOL,    // pool_out = maxpool2x2(z*scale + skip) + routing bytes   (pooled block tail; ping-pong kernel only)
+       EPI_DGRAD_ADDPOOL }; // dx = acc + unpool(dout) through the routing bytes  (ping-pong kernel only)
 
 template <int MT, int NT, int MODE>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], const bool (&okn)[NT],

@@ -371,6 +371,52 @@ def conv3x3_dgrad(dz, wpk_bwd, cin: int, dx, act=None, add=None, slope: float = 
           "fdet_conv3x3_dgrad")
 
 
+def pool_fusion_supported(cout: int, cin: int, H: int, W: int) -> bool:
+    """Pooled residual blocks whose tail runs inside the conv epilogues (fdet_conv3x3_fwd_pool_bf16x3)."""
+    return cout % 32 == 0 and cin % 16 == 0 and H % 2 == 0 and W % 2 == 0 and H >= 2 and 2 <= W <= 62
+
+
+def conv3x3_fwd_pool(x, wpk, bias, skip, drop_scale, out_pooled, route, slope: float = 0.2):
+    """out_pooled = maxpool2x2(lrelu(conv(x)+bias)*drop_scale + skip); route: uint8 routing bytes or None (eval)."""
+    Nn, cin, H, W = x.shape
+    cout = bias.shape[0]
+    if wpk.numel() != packed_sizes(cout, cin)[0]:
+        raise ValueError("conv3x3_fwd_pool: packed weight size does not match (Cout,Cin)")
+    _chk4(skip, (Nn, cout, H, W), "skip")
+    _chk4(out_pooled, (Nn, cout, H // 2, W // 2), "out_pooled")
+    if route is not None:
+        _chk4(route, (Nn, cout, H // 2, W // 2), "route")
+    if drop_scale is not None:
+        _chk4(drop_scale, (Nn, cout), "drop_scale")
+    check(lib().fdet_conv3x3_fwd_pool_bf16x3(ptr(x), ptr(wpk), ptr(bias), ptr(skip), ptr(drop_scale), ptr(out_pooled),
+                                             ptr(route, torch.uint8), Nn, cin, cout, H, W, float(slope), stream()),
+          "fdet_conv3x3_fwd_pool_bf16x3")
+
+
+def conv3x3_dgrad_unpool(dz, wpk_bwd, cin: int, dout_pooled, route, dx, slope: float = 0.2):
+    """dx = conv^T(dz) + unpool(dout_pooled) through the routing bytes of the forward pass."""
+    Nn, cout, H, W = dz.shape
+    if wpk_bwd.numel() != packed_sizes(cout, cin)[1]:
+        raise ValueError("conv3x3_dgrad_unpool: packed weight size does not match (Cout,Cin)")
+    _chk4(dx, (Nn, cin, H, W), "dx")
+    _chk4(dout_pooled, (Nn, cin, H // 2, W // 2), "dout_pooled")
+    _chk4(route, (Nn, cin, H // 2, W // 2), "route")
+    check(lib().fdet_conv3x3_dgrad_unpool_bf16x3(ptr(dz), ptr(wpk_bwd), ptr(dout_pooled), ptr(route, torch.uint8), ptr(dx),
+                                                 Nn, cin, cout, H, W, float(slope), stream()),
+          "fdet_conv3x3_dgrad_unpool_bf16x3")
+
+
+def pool_route_bwd(dout_pooled, route, drop_scale, dz2, slope: float = 0.2):
+    """dz2 = unpool(dout_pooled) * drop_scale * lrelu'(c), from the routing bytes alone."""
+    Nn, F_, H, W = dz2.shape
+    _chk4(dout_pooled, (Nn, F_, H // 2, W // 2), "dout_pooled")
+    _chk4(route, (Nn, F_, H // 2, W // 2), "route")
+    if drop_scale is not None:
+        _chk4(drop_scale, (Nn, F_), "drop_scale")
+    check(lib().fdet_pool_route_bwd(ptr(dout_pooled), ptr(route, torch.uint8), ptr(drop_scale), ptr(dz2), Nn, F_, H, W,
+                                    float(slope), stream()), "fdet_pool_route_bwd")
+
+
 def conv3x3_wgrad_ws_bytes(Nn, cin, cout, H, W) -> int:
     """Workspace that serves BOTH precisions of conv3x3_wgrad."""
     return max(int(lib().fdet_conv3x3_wgrad_ws_bytes(Nn, cin, cout, H, W)),

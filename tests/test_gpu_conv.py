@@ -244,3 +244,78 @@ def test_block_chain_fwd_bwd(hp, cfg):
         close(dz1_d[k], z1[k].grad)
         close(dz2_d[k], z2[k].grad)
     close(dx_d, xr.grad)
+
+
+POOL_SHAPES = [(3, 64, 60, 60), (4, 64, 30, 30), (2, 32, 30, 30), (5, 64, 28, 30), (1, 64, 6, 58), (2, 128, 30, 30),
+               (33, 64, 60, 60), (1, 32, 2, 62), (2, 32, 4, 10)]
+
+
+@pytest.mark.parametrize("shape", POOL_SHAPES)
+def test_pooled_block_fused_into_conv_epilogues(hp, shape):
+    """Pooled residual-block tail inside the conv kernels (fdet_conv3x3_fwd_pool_bf16x3 / fdet_pool_route_bwd /
+    fdet_conv3x3_dgrad_unpool_bf16x3) against torch fp32 CPU of models/PoolResnet.py:36-42 and its autograd.
+    Values: 1e-4 of the tensor scale.  Routing: the pooled VALUE and its gradient are what is compared, so a window
+    whose two largest entries differ by less than the conv's rounding may legitimately route to the other one --
+    such windows are excluded where the runner-up is within 1e-4 (counted, must stay rare)."""
+    N, C, H, W = shape
+    assert hp.pool_fusion_supported(C, C, H, W)
+    g = torch.Generator().manual_seed(N * 7 + C + H + W)
+    a = torch.randn(N, C, H, W, generator=g)
+    w2 = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    b2 = torch.randn(C, generator=g)
+    skip = torch.randn(N, C, H, W, generator=g)
+    scale = (torch.rand(N, C, generator=g) > 0.25).float() / 0.75
+    nf, nb = hp.packed_sizes(C, C)
+    wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda")
+    hp.pack_conv3x3_weights(w2.cuda(), wf, wb, x3=True)
+    out = torch.full((N, C, H // 2, W // 2), float("nan"), device="cuda")
+    route = torch.full((N, C, H // 2, W // 2), 255, dtype=torch.uint8, device="cuda")
+    hp.conv3x3_fwd_pool(a.cuda(), wf, b2.cuda(), skip.cuda(), scale.cuda(), out, route)
+    c = F.leaky_relu(F.conv2d(a, w2, b2, padding=1), 0.2)
+    e = c * scale[:, :, None, None] + skip
+    ref, ref_idx = F.max_pool2d(e, 2, return_indices=True)
+    close(out, ref)
+    # eval flavour: no routing bytes, no dropout
+    out_e = torch.full_like(out, float("nan"))
+    hp.conv3x3_fwd_pool(a.cuda(), wf, b2.cuda(), skip.cuda(), None, out_e, None)
+    close(out_e, F.max_pool2d(c + skip, 2))
+    # routing bytes: argmax (ATen scan order) and sign bits of c, wherever the decision is not within rounding
+    r = route.cpu().int()
+    arg = (r >> 4) & 3
+    wy = torch.arange(H // 2).view(1, 1, -1, 1) * 2
+    wx = torch.arange(W // 2).view(1, 1, 1, -1) * 2
+    ref_arg = ((ref_idx // W) - wy) * 2 + ((ref_idx % W) - wx)
+    ew = e.unfold(2, 2, 2).unfold(3, 2, 2).reshape(N, C, H // 2, W // 2, 4)
+    top2 = ew.topk(2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > 1e-4 * max(1.0, float(e.abs().max()))
+    assert float(decided.float().mean()) > 0.99
+    assert torch.equal(arg[decided], ref_arg[decided].int())
+    cw = c.unfold(2, 2, 2).unfold(3, 2, 2).reshape(N, C, H // 2, W // 2, 4)
+    for k in range(4):
+        clear = cw[..., k].abs() > 1e-4 * max(1.0, float(c.abs().max()))
+        assert torch.equal(((r >> k) & 1)[clear].bool(), (cw[..., k] > 0)[clear])
+    assert int((r >> 6).max()) == 0
+    # backward: dz2 = unpool(dout)*scale*lrelu'(c) from the bytes alone
+    dout = torch.randn(N, C, H // 2, W // 2, generator=g)
+    dz2 = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.pool_route_bwd(dout.cuda(), route, scale.cuda(), dz2)
+    # reference built from the KERNEL's routing (the decision itself was checked above)
+    de_ref = torch.zeros(N, C, H // 2, W // 2, 4)
+    de_ref.scatter_(-1, arg.long().unsqueeze(-1), dout.unsqueeze(-1))
+    de_full = de_ref.reshape(N, C, H // 2, W // 2, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H, W)
+    bits = torch.stack([(r >> k) & 1 for k in range(4)], -1).reshape(N, C, H // 2, W // 2, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H, W)
+    dz2_ref = de_full * scale[:, :, None, None] * torch.where(bits > 0, 1.0, 0.2)
+    assert torch.equal(dz2.cpu(), dz2_ref)                     # pure routing: bit-exact
+    # ... and the skip-path gradient added inside conv1's data gradient
+    w1 = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    wf1 = torch.empty(nf, device="cuda"); wb1 = torch.empty(nb, device="cuda")
+    hp.pack_conv3x3_weights(w1.cuda(), wf1, wb1, x3=True)
+    dz1 = torch.randn(N, C, H, W, generator=g)
+    dx = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.conv3x3_dgrad_unpool(dz1.cuda(), wb1, C, dout.cuda(), route, dx)
+    close(dx, F.conv_transpose2d(dz1, w1, padding=1) + de_full)
+    # end to end against autograd of the reference block tail (decided windows only)
+    er = e.clone().requires_grad_(True)
+    F.max_pool2d(er, 2).backward(dout)
+    full_decided = decided.reshape(N, C, H // 2, W // 2, 1, 1).expand(-1, -1, -1, -1, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H, W)
+    assert torch.equal(de_full[full_decided], er.grad[full_decided])
