@@ -30,6 +30,27 @@ using namespace fdet;
 
 namespace {
 
+// Issue arbitration between the two waves of a SIMD (MI355X_MICROARCH.md, "Two waves per SIMD"): a wave whose next
+// instruction is an MFMA that waits for the busy matrix pipe keeps winning the vector issue port by priority / age, and
+// its partner gets about one VALU instruction per MFMA.  The MFMA stream therefore yields explicitly: after every MFMA
+// it sleeps FDET_PP_NOP cycles (s_nop: not a candidate for issue), which hands the partner group's split / epilogue
+// VALU ~4 issue slots per MFMA, and runs at raised priority so that it gets the port back the moment the pipe frees.
+#ifndef FDET_PP_NOP
+#define FDET_PP_NOP 0
+#endif
+#ifndef FDET_PP_ABL
+#define FDET_PP_ABL 0      // diagnostic builds only: 1 = empty memory segments, 2 = no B prefetch in the MFMA segment, 4 = no MFMAs, 8 = no LDS writes / weight DMA
+#endif
+#ifndef FDET_PP_PRIO
+#define FDET_PP_PRIO 0
+#endif
+#define PP_STR2(x) #x
+#define PP_STR(x) PP_STR2(x)
+#if FDET_PP_NOP > 0
+#define PP_YIELD() { asm volatile("s_nop " PP_STR(FDET_PP_NOP) " - 1"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PP_YIELD()
+#endif
 constexpr int GTHR = 256;     // threads per group
 constexpr int PTHR = 512;     // threads per workgroup
 __host__ __device__ constexpr int nbs_pp(int vw) { return vw == 4 ? 1 : (vw == 2 ? 2 : 3); }
@@ -48,30 +69,57 @@ struct PpArgs {
   unsigned magic_bpi;
   int ntiles_mb;             // N * bpi
   int rowpair;               // 1: a wave owns 2 rows x 32 columns (WP in {32,64}); 0: 64 consecutive padded positions
+  long long* stamps;         // diagnostic build (-DFDET_PP_STAMPS, tools/probe) only; null otherwise
 };
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-// 4x4 dword transpose across each quad of lanes: register i of lane j <-> register j of lane i
-__device__ __forceinline__ f32x4 quad_transpose4(float v0, float v1, float v2, float v3, bool b0, bool b1) {
-  float v[4] = {v0, v1, v2, v3};
-#pragma unroll
-  for (int k = 0; k < 4; k += 2) {
-    const float lo = v[k], hi = v[k + 1];
-    const float recv = dpp_quad<0xB1>(b0 ? lo : hi);            // quad_perm [1,0,3,2]
-    v[k] = b0 ? recv : lo;
-    v[k + 1] = b0 ? hi : recv;
-  }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const float lo = v[k], hi = v[k + 2];
-    const float recv = dpp_quad<0x4E>(b1 ? lo : hi);            // quad_perm [2,3,0,1]
-    v[k] = b1 ? recv : lo;
-    v[k + 2] = b1 ? hi : recv;
-  }
-  return f32x4{v[0], v[1], v[2], v[3]};
+#ifdef FDET_PP_STAMPS
+// per workgroup (first 32 only) and wave: [0] = HW_ID, [1] = phases, then per phase {start, end of work} in shader clocks
+#define PP_STAMP(SLOT) { __builtin_amdgcn_sched_barrier(0); if (p.stamps && blockIdx.x < 32 && lane == 0 && (SLOT) < 250) p.stamps[((size_t)blockIdx.x * 8 + wid) * 256 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PP_STAMP(SLOT) {}
+#endif
+
+// 4x4 dword transpose across each quad of lanes: register i of lane j <-> register j of lane i, for TWO register
+// quads at once.  Two exchange steps (lane ^ 1 on registers (0,1),(2,3); lane ^ 2 on (0,2),(1,3)); every new value is
+// ONE v_cndmask_b32_dpp (D = vcc ? own : other lane's), two instructions per exchanged pair where round 1's builtin
+// form (select, DPP move, two selects) cost four.  Written as asm because hipcc turns `cond ? own : dpp(other)` into a
+// DPP move under a narrowed EXEC, which reads zeros from the disabled source lanes.
+//   mb0 / mb1: wave masks of (lane & 1) / (lane & 2); nb0 / nb1 their complements.
+// Hazards inside the string: a VGPR written by a VALU needs two wait states before a DPP read (s_nop 1 between the
+// steps; within a step every DPP source is an input).  The inputs are MFMA results of an earlier phase (a barrier and
+// hundreds of cycles away), so no XDL-write hazard reaches this code.
+__device__ __forceinline__ void quad_transpose8(const float (&v)[8], float (&c)[8], unsigned long long mb0,
+                                                unsigned long long nb0, unsigned long long mb1, unsigned long long nb1) {
+  float a0, a1, a2, a3, a4, a5, a6, a7;
+  asm volatile(
+      "s_mov_b64 vcc, %[mb0]\n\t"
+      "v_cndmask_b32_dpp %[a1], %[v0], %[v1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[a3], %[v2], %[v3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[a5], %[v4], %[v5], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[a7], %[v6], %[v7], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_mov_b64 vcc, %[nb0]\n\t"
+      "v_cndmask_b32_dpp %[a0], %[v1], %[v0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[a2], %[v3], %[v2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[a4], %[v5], %[v4], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[a6], %[v7], %[v6], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_mov_b64 vcc, %[mb1]\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32_dpp %[c2], %[a0], %[a2], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[c3], %[a1], %[a3], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[c6], %[a4], %[a6], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[c7], %[a5], %[a7], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_mov_b64 vcc, %[nb1]\n\t"
+      "v_cndmask_b32_dpp %[c0], %[a2], %[a0], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[c1], %[a3], %[a1], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[c4], %[a6], %[a4], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %[c5], %[a7], %[a5], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1"
+      : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [a4] "=&v"(a4), [a5] "=&v"(a5), [a6] "=&v"(a6),
+        [a7] "=&v"(a7), [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3]), [c4] "=&v"(c[4]),
+        [c5] "=&v"(c[5]), [c6] "=&v"(c[6]), [c7] "=&v"(c[7])
+      : [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]),
+        [v7] "v"(v[7]), [mb0] "s"(mb0), [nb0] "s"(nb0), [mb1] "s"(mb1), [nb1] "s"(nb1)
+      : "vcc");
 }
 
 // first maximum in window scan order wins, NaN is a maximum (ATen max_pool2d; fdet_tail.hip)
@@ -83,95 +131,147 @@ __device__ __forceinline__ void upd(float v, int k, float& m, int& arg) {
   { if ((NV) == 4) __builtin_memcpy(&(DST), (SRC), 16); else if ((NV) == 3) __builtin_memcpy(&(DST), (SRC), 12); \
     else if ((NV) == 2) __builtin_memcpy(&(DST), (SRC), 8); else if ((NV) == 1) __builtin_memcpy(&(DST), (SRC), 4); }
 
-// Epilogue of one tile.  The MFMA leaves lane = position, 4 registers = 4 consecutive channels; a 4x4 dword
+// Epilogue of one tile, in two parts so that its global loads travel under the LDS writes of the next chunk and
+// under the register transposes.  The MFMA leaves lane = position, 4 registers = 4 consecutive channels; a 4x4 dword
 // transpose across each quad of lanes gives lane = channel, 4 registers = 4 consecutive columns of one row:
 // 16-byte global accesses over 128-byte runs.  n = 0,1 are the wave's two 32-position blocks (rowpair: the same
 // 32 columns of two adjacent rows).
-template <int MT, int MODE>
-__device__ __forceinline__ void epilogue_pp(const PpArgs& p, f32x16 (&acc)[MT][2], int img, int y0, int qwave,
-                                            int nstride, int cob0, int l31, int half) {
+struct EpiGeo {
+  int nv[2], idx0[2];      // valid columns (0..4) and element index of (channel cob0+4half+j, row, column) per n
+  int npair, pidx0;        // pooled modes: valid windows (0..2) and pooled element index
+};
+
+template <int MODE>
+__device__ __forceinline__ EpiGeo epi_geometry(const PpArgs& p, int img, int y0, int qwave, int nstride, int cob0, int l31, int half) {
   const ConvArgs& a = p.c;
-  const float* __restrict__ g_bias = a.bias;
-  const float* __restrict__ g_scale = a.scale;
-  float* __restrict__ g_full = a.y_full;
-  float* __restrict__ g_out = a.y_out;
-  const int HW = a.H * a.W;
-  const bool b0 = l31 & 1, b1 = l31 & 2;
-  const int j = l31 & 3;
-  constexpr bool FWD = MODE == EPI_FWD_FULL || MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT || MODE == EPI_FWD_POOL;
   constexpr bool POOLM = MODE == EPI_FWD_POOL || MODE == EPI_DGRAD_ADDPOOL;
-  constexpr bool HAS_LD = MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT || MODE == EPI_DGRAD_ACT || MODE == EPI_DGRAD_ADD || MODE == EPI_FWD_POOL;
-  const float* __restrict__ src = MODE == EPI_DGRAD_ACT ? a.act : a.skip;
-  int nv[2], idx0[2], yrow0 = 0, ox0 = 0;
+  // (FDET_PP_ABL & 16, timing experiment only, WRONG results: lanes 0..7 of a store address 128 contiguous bytes)
+  const int HW = a.H * a.W, j = (FDET_PP_ABL & 16) ? (l31 >> 3) : (l31 & 3);
+  EpiGeo e;
+  int yrow0 = 0, ox0 = 0;
   bool ok0 = false;
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    const int q4 = qwave + n * nstride + (l31 & ~3);
+    const int q4 = qwave + n * nstride + ((FDET_PP_ABL & 16) ? 4 * (l31 & 7) : (l31 & ~3));
     const int tr = fdiv(q4, p.magic_wp), ox = q4 - tr * a.WP;
     const int y = y0 + tr;
     const bool ok = tr < a.R && y < a.H && ox < a.W;
-    nv[n] = ok ? min(4, a.W - ox) : 0;
-    idx0[n] = (ok ? ((img * a.Cout) * a.H + y) * a.W + ox : 0) + (cob0 + 4 * half + j) * HW;   // + (32m + 8g)*HW
+    e.nv[n] = ok ? min(4, a.W - ox) : 0;
+    e.idx0[n] = (ok ? ((img * a.Cout) * a.H + y) * a.W + ox : 0) + (cob0 + 4 * half + j) * HW;   // + (32m + 8g)*HW
     if (n == 0) { yrow0 = y; ox0 = ox; ok0 = ok; }
   }
   // pooled geometry (rowpair tiles only: n = 0/1 are rows y, y+1 with y even, same columns)
   const int Hp = a.H >> 1, Wp = a.W >> 1;
-  const int npair = (POOLM && ok0) ? min(2, (a.W - ox0) >> 1) : 0;
-  const int pidx0 = POOLM ? ((ok0 ? ((img * a.Cout) * Hp + (yrow0 >> 1)) * Wp + (ox0 >> 1) : 0) + (cob0 + 4 * half + j) * Hp * Wp) : 0;
+  e.npair = (POOLM && ok0) ? min(2, (a.W - ox0) >> 1) : 0;
+  e.pidx0 = POOLM ? ((ok0 ? ((img * a.Cout) * Hp + (yrow0 >> 1)) * Wp + (ox0 >> 1) : 0) + (cob0 + 4 * half + j) * Hp * Wp) : 0;
+  return e;
+}
+
+// part 1: every global load of the epilogue (nothing consumes them here)
+template <int MT, int MODE>
+__device__ __forceinline__ void epi_loads(const PpArgs& p, const EpiGeo& e, f32x4 (&u)[MT][2][4], float (&dg)[MT][4][2],
+                                          unsigned (&mk)[MT][4], float (&bz)[MT][4], float (&sc)[MT][4], int img, int cob0,
+                                          int l31, int half) {
+  const ConvArgs& a = p.c;
+  {
+    // bias / dropout scale of this lane's channels: requested HERE, ahead of every store of the epilogue -- a load issued
+    // after stores is only usable once those stores have been acknowledged (vmcnt counts in order): 2-3 k cycles each
+    constexpr bool FWD_ = MODE == EPI_FWD_FULL || MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT || MODE == EPI_FWD_POOL;
+    const int j_ = l31 & 3;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = cob0 + 32 * m + 8 * g + 4 * half + j_;
+        bz[m][g] = FWD_ ? a.bias[ch] : 0.f;
+        sc[m][g] = ((MODE == EPI_FWD_BOTH || MODE == EPI_FWD_POOL) && a.scale) ? a.scale[img * a.Cout + ch] : 1.f;
+      }
+  }
+  constexpr bool HAS_LD = MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT || MODE == EPI_DGRAD_ACT || MODE == EPI_DGRAD_ADD || MODE == EPI_FWD_POOL;
+  const float* __restrict__ src = MODE == EPI_DGRAD_ACT ? a.act : a.skip;
+  const int HW = a.H * a.W;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) u[m][n][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (HAS_LD) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      // the branch on the valid count sits outside the load loops (a branch per load serialises them)
+      if (e.nv[n] == 4) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) __builtin_memcpy(&u[m][n][g], src + e.idx0[n] + (32 * m + 8 * g) * HW, 16);
+      } else if (e.nv[n] > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) PP_VEC_LD(u[m][n][g], src + e.idx0[n] + (32 * m + 8 * g) * HW, e.nv[n])
+      }
+    }
+  }
+  if (MODE == EPI_DGRAD_ADDPOOL) {
+    const float* __restrict__ g_din = p.q.pool_din;
+    const unsigned char* __restrict__ g_mk = p.q.mask_in;
+    const int HWp = (a.H >> 1) * (a.W >> 1);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int pi = e.pidx0 + (32 * m + 8 * g) * HWp;
+        dg[m][g][0] = dg[m][g][1] = 0.f;
+        mk[m][g] = 0u;
+        if (e.npair == 2) { __builtin_memcpy(dg[m][g], g_din + pi, 8); mk[m][g] = (unsigned)g_mk[pi] | ((unsigned)g_mk[pi + 1] << 8); }
+        else if (e.npair == 1) { dg[m][g][0] = g_din[pi]; mk[m][g] = g_mk[pi]; }
+      }
+  }
+}
+
+// part 2: transposes, arithmetic, stores
+template <int MT, int MODE>
+__device__ __forceinline__ void epi_finish(const PpArgs& p, const EpiGeo& e, f32x16 (&acc)[MT][2], f32x4 (&u)[MT][2][4],
+                                           float (&dg)[MT][4][2], unsigned (&mk)[MT][4], const float (&bzm)[MT][4],
+                                           const float (&scm)[MT][4], int img, int cob0, int l31, int half) {
+  const ConvArgs& a = p.c;
+  float* __restrict__ g_full = a.y_full;
+  float* __restrict__ g_out = a.y_out;
+  const int HW = a.H * a.W, HWp = (a.H >> 1) * (a.W >> 1);
+  const unsigned long long mb0 = 0xAAAAAAAAAAAAAAAAull, nb0 = ~mb0, mb1 = 0xCCCCCCCCCCCCCCCCull, nb1 = ~mb1;   // lane & 1, lane & 2
+  constexpr bool FWD = MODE == EPI_FWD_FULL || MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT || MODE == EPI_FWD_POOL;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     float bz[4], sc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int ch = cob0 + 32 * m + 8 * g + 4 * half + j;
-      bz[g] = FWD ? g_bias[ch] : 0.f;
-      sc[g] = ((MODE == EPI_FWD_BOTH || MODE == EPI_FWD_POOL) && g_scale) ? g_scale[img * a.Cout + ch] : 1.f;
-    }
-    f32x4 t[2][4], u[2][4];
+    for (int g = 0; g < 4; ++g) { bz[g] = bzm[m][g]; sc[g] = scm[m][g]; }
+    f32x4 t[2][4];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) u[n][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (HAS_LD) {
+      for (int g = 0; g < 4; g += 2) {
+        float vi[8], co[8];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        // the branch on the valid count sits outside the load loop (a branch per load serialises them)
-        if (nv[n] == 4) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) __builtin_memcpy(&u[n][g], src + idx0[n] + (32 * m + 8 * g) * HW, 16);
-        } else if (nv[n] > 0) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) PP_VEC_LD(u[n][g], src + idx0[n] + (32 * m + 8 * g) * HW, nv[n])
-        }
+        for (int r = 0; r < 8; ++r) vi[r] = acc[m][n][4 * g + r];
+        quad_transpose8(vi, co, mb0, nb0, mb1, nb1);
+        t[n][g] = f32x4{co[0], co[1], co[2], co[3]};
+        t[n][g + 1] = f32x4{co[4], co[5], co[6], co[7]};
       }
-    }
     if (MODE == EPI_DGRAD_ADDPOOL) {
       // unpool(dout): window (row pair, column pair pc) sends its gradient to element arg = 2*row + col
-      const float* __restrict__ g_din = p.q.pool_din;
-      const unsigned char* __restrict__ g_mk = p.q.mask_in;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int pi = pidx0 + (32 * m + 8 * g) * Hp * Wp;
-        float dg[2] = {0.f, 0.f};
-        unsigned mk[2] = {0u, 0u};
-        if (npair == 2) { __builtin_memcpy(dg, g_din + pi, 8); mk[0] = g_mk[pi]; mk[1] = g_mk[pi + 1]; }
-        else if (npair == 1) { dg[0] = g_din[pi]; mk[0] = g_mk[pi]; }
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-          const int arg = (mk[pc] >> 4) & 3;
-          u[0][g][2 * pc] = arg == 0 ? dg[pc] : 0.f;
-          u[0][g][2 * pc + 1] = arg == 1 ? dg[pc] : 0.f;
-          u[1][g][2 * pc] = arg == 2 ? dg[pc] : 0.f;
-          u[1][g][2 * pc + 1] = arg == 3 ? dg[pc] : 0.f;
-        }
-      }
-    }
-    // (memory requests first, the register transposes of the accumulators travel under their latency)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        t[n][g] = quad_transpose4(acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3], b0, b1);
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+          const int arg = (mk[m][g] >> (8 * pc + 4)) & 3;
+          const float gv = dg[m][g][pc];
+          u[m][0][g][2 * pc] = arg == 0 ? gv : 0.f;
+          u[m][0][g][2 * pc + 1] = arg == 1 ? gv : 0.f;
+          u[m][1][g][2 * pc] = arg == 2 ? gv : 0.f;
+          u[m][1][g][2 * pc + 1] = arg == 3 ? gv : 0.f;
+        }
+    }
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -181,13 +281,13 @@ __device__ __forceinline__ void epilogue_pp(const PpArgs& p, f32x16 (&acc)[MT][2
           float z = t[n][g][i];
           if (FWD) {
             const float w_ = z + bz[g];
-            z = w_ > 0.f ? w_ : w_ * a.slope;
-            if (MODE == EPI_FWD_BOTH || MODE == EPI_FWD_POOL) u[n][g][i] = z * sc[g] + u[n][g][i];
-            if (MODE == EPI_FWD_OUT) u[n][g][i] = z + u[n][g][i];
+            z = fmaxf(w_, w_ * a.slope);              // == w > 0 ? w : w*slope for 0 <= slope <= 1 (NaN stays NaN)
+            if (MODE == EPI_FWD_BOTH || MODE == EPI_FWD_POOL) u[m][n][g][i] = z * sc[g] + u[m][n][g][i];
+            if (MODE == EPI_FWD_OUT) u[m][n][g][i] = z + u[m][n][g][i];
           } else if (MODE == EPI_DGRAD_ACT) {
-            z *= (u[n][g][i] > 0.f) ? 1.f : a.slope;
+            z *= (u[m][n][g][i] > 0.f) ? 1.f : a.slope;
           } else {
-            z += u[n][g][i];
+            z += u[m][n][g][i];
           }
           t[n][g][i] = z;
         }
@@ -202,19 +302,19 @@ __device__ __forceinline__ void epilogue_pp(const PpArgs& p, f32x16 (&acc)[MT][2
         for (int pc = 0; pc < 2; ++pc) {
           float mx = -INFINITY;
           int arg = 0;
-          upd(u[0][g][2 * pc], 0, mx, arg);
-          upd(u[0][g][2 * pc + 1], 1, mx, arg);
-          upd(u[1][g][2 * pc], 2, mx, arg);
-          upd(u[1][g][2 * pc + 1], 3, mx, arg);
+          upd(u[m][0][g][2 * pc], 0, mx, arg);
+          upd(u[m][0][g][2 * pc + 1], 1, mx, arg);
+          upd(u[m][1][g][2 * pc], 2, mx, arg);
+          upd(u[m][1][g][2 * pc + 1], 3, mx, arg);
           po[pc] = mx;
           pm[pc] = (unsigned char)((t[0][g][2 * pc] > 0.f ? 1 : 0) | (t[0][g][2 * pc + 1] > 0.f ? 2 : 0) |
                                    (t[1][g][2 * pc] > 0.f ? 4 : 0) | (t[1][g][2 * pc + 1] > 0.f ? 8 : 0) | (arg << 4));
         }
-        const int pi = pidx0 + (32 * m + 8 * g) * Hp * Wp;
-        if (npair == 2) {
+        const int pi = e.pidx0 + (32 * m + 8 * g) * HWp;
+        if (e.npair == 2) {
           __builtin_memcpy(g_pool + pi, po, 8);
           if (g_mk) { g_mk[pi] = pm[0]; g_mk[pi + 1] = pm[1]; }
-        } else if (npair == 1) {
+        } else if (e.npair == 1) {
           g_pool[pi] = po[0];
           if (g_mk) g_mk[pi] = pm[0];
         }
@@ -224,11 +324,11 @@ __device__ __forceinline__ void epilogue_pp(const PpArgs& p, f32x16 (&acc)[MT][2
       for (int n = 0; n < 2; ++n) {
 #define PP_ST(BYTES)                                                                               \
   _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                  \
-    const int idx_ = idx0[n] + (32 * m + 8 * g) * HW;                                              \
+    const int idx_ = e.idx0[n] + (32 * m + 8 * g) * HW;                                            \
     if (MODE != EPI_FWD_OUT) __builtin_memcpy(g_full + idx_, &t[n][g], BYTES);                     \
-    if (MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT) __builtin_memcpy(g_out + idx_, &u[n][g], BYTES); \
+    if (MODE == EPI_FWD_BOTH || MODE == EPI_FWD_OUT) __builtin_memcpy(g_out + idx_, &u[m][n][g], BYTES); \
   }
-        if (nv[n] == 4) { PP_ST(16) } else if (nv[n] == 3) { PP_ST(12) } else if (nv[n] == 2) { PP_ST(8) } else if (nv[n] == 1) { PP_ST(4) }
+        if (e.nv[n] == 4) { PP_ST(16) } else if (e.nv[n] == 3) { PP_ST(12) } else if (e.nv[n] == 2) { PP_ST(8) } else if (e.nv[n] == 1) { PP_ST(4) }
 #undef PP_ST
       }
     }
@@ -275,6 +375,15 @@ k_conv3x3_x3_pp(const PpArgs p) {
   const int K = n_g * nch;                            // this group's MFMA segments
   const int K0 = ((nt_all + 1) >> 1) * nch;           // group 0's (>= group 1's)
 
+  if (a.stagger > 0) {
+    // De-synchronise the CUs.  Every workgroup runs the same phase sequence, so without this all 256 CUs issue their
+    // epilogue store bursts (and their chunk loads) in the same few microseconds and HBM alternates between saturated
+    // and idle: measured 8 k cycles for an epilogue segment that takes 3 k on an otherwise quiet chip.  Workgroup i
+    // starts (i / 8) % 8 eighths of a tile period late (the 8 workgroups of a "column" sit on the 8 XCDs).
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    const long long wait = (long long)a.stagger * ((blockIdx.x >> 3) & 7);
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
   {  // zero the activation buffers once: halo / pad slots are never written again
     f32x4* z = reinterpret_cast<f32x4*>(lds + 4 * A_UNITS);
     for (int t = tid; t < 8 * PT; t += PTHR) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -372,24 +481,47 @@ k_conv3x3_x3_pp(const PpArgs p) {
   const int a_off = half * MB + l31;                  // + tap*2*MB + m*32 ; lo: + A_UNITS
   const int b_off = half * PT + qwave + l31;          // + tapoff + n*nstride ; lo: + 2*PT
 
-  // ---- prologue: both groups stage their first chunk, group 0 fetches the first weight panel
+  // ---- prologue: both groups stage their first chunk; the first weight panel arrives (every wave waits for its own
+  // LDS-DMA pieces, the barrier covers the others)
   __syncthreads();                                    // zero fill complete
+  if (grp == 1) PP_DMA_W(0)
   if (K > 0) {
     PP_TILE_SRC(0)
     cur_img = st_img; cur_y0 = st_y0;
     PP_ISSUE_B(0)
+    PP_WRITE_B()
   }
-  if (grp == 0) PP_DMA_W(0)
-  if (K > 0) PP_WRITE_B()
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // Phase ph: group (ph & 1) is in its MFMA segment, the other one in its memory segment.  Group g's segment number
+  // ks (chunk ks % nch of its tile ks / nch) runs in phase 2*ks + g; its activations were loaded into registers
+  // during segment ks-1 (one phase of MFMAs hides the HBM latency) and written to LDS in the memory segment between.
+  // Weight panel of segment s (both groups: phases 2s and 2s+1) lives in ring slot s & 1, free from the end of phase
+  // 2s-3.  GROUP 1 requests it at the start of its memory segment in phase 2s-2 and waits for it at the END of its MFMA
+  // segment in phase 2s-1 -- a whole phase later, so the wait (vmcnt counts in order: it also covers the epilogue stores
+  // issued after the request) costs nothing, and the barrier that ends phase 2s-1 publishes the slot.
   const int nphase = 2 * K0 + 1;
+#ifdef FDET_PP_STAMPS
+  if (p.stamps && blockIdx.x < 32 && lane == 0) {
+    p.stamps[((size_t)blockIdx.x * 8 + wid) * 256 + 0] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+    p.stamps[((size_t)blockIdx.x * 8 + wid) * 256 + 1] = nphase;
+  }
+#endif
   for (int ph = 0; ph < nphase; ++ph) {
+    PP_STAMP(2 + 2 * ph)
     const int d = ph - grp;
     if (d >= 0 && (d & 1) == 0) {
-      // =========================== MFMA segment: chunk ks % nch of this group's current tile
+      // =========================== MFMA segment
       const int ks = d >> 1;
       if (ks < K) {
+        __builtin_amdgcn_s_setprio(FDET_PP_PRIO);     // this wave's MFMAs before the partner group's VALU / LDS-store stream
+        const int kn = ks + 1;                        // the loads of the next segment travel under this one
+        if (kn < K && !(FDET_PP_ABL & 2)) {
+          const int cn = kn % nch;
+          if (cn == 0) PP_TILE_SRC(kn / nch)
+          PP_ISSUE_B(cn)
+        }
         const bf16x8* Aw = lds + (ks & 1) * 2 * A_UNITS + a_off;
         const bf16x8* Bw = Bbuf + b_off;
         bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
@@ -398,7 +530,7 @@ k_conv3x3_x3_pp(const PpArgs p) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) { bh[0][n] = Bw[tapoff[0] + n * nstride]; bl[0][n] = Bw[2 * PT + tapoff[0] + n * nstride]; }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < ((FDET_PP_ABL & 4) ? 0 : 9); ++t) {
           const int cur = t & 1, nxt = cur ^ 1;
           if (t + 1 < 9) {                            // fragments of tap t+1 travel under the MFMAs of tap t
 #pragma unroll
@@ -417,40 +549,59 @@ k_conv3x3_x3_pp(const PpArgs p) {
           for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
+            {
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][m], bl[cur][n], acc[m][n], 0, 0, 0);
+              PP_YIELD()
+            }
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][m], bh[cur][n], acc[m][n], 0, 0, 0);
+              PP_YIELD()
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][m], bh[cur][n], acc[m][n], 0, 0, 0);
+              PP_YIELD()
             }
           __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_s_setprio(0);
       }
-    } else if (d >= 0) {
+      if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the panel requested one phase ago (see above)
+    } else if (d < 0) {
+      if (1 < K0 && !(FDET_PP_ABL & 8)) PP_DMA_W(1)   // group 1, phase 0: panel of segment 1 (waited for at the end of phase 1)
+    } else if (!(FDET_PP_ABL & 1)) {
       // =========================== memory segment: everything this group needs before its segment kn
       const int kn = (d + 1) >> 1;
       const int cn = kn % nch;
-      if (kn < K) {
-        if (cn == 0) PP_TILE_SRC(kn / nch)
-        PP_ISSUE_B(cn)
-      }
-      if (grp == 0 && kn < K0) PP_DMA_W(kn)           // also serves group 1's segment kn, one phase later
-      if (cn == 0 && kn >= nch && kn <= K) {          // the tile finished by segment kn-1
-        epilogue_pp<MT, MODE>(p, acc, cur_img, cur_y0, qwave, nstride, mb * MB, l31, half);
+      const bool tile_done = cn == 0 && kn >= nch && kn <= K;      // segment kn-1 completed a tile
+      if (tile_done) {
+        const EpiGeo eg = epi_geometry<MODE>(p, cur_img, cur_y0, qwave, nstride, mb * MB, l31, half);
+        f32x4 u[MT][2][4];
+        float dg[MT][4][2];
+        unsigned mk[MT][4];
+        float bzm[MT][4], scm[MT][4];
+        if (kn == 2 * nch) PP_STAMP(200)
+        epi_loads<MT, MODE>(p, eg, u, dg, mk, bzm, scm, cur_img, mb * MB, l31, half);   // issue; the LDS writes and the transposes hide their latency
+        if (kn == 2 * nch) PP_STAMP(201)
+        if (kn < K && !(FDET_PP_ABL & 8)) PP_WRITE_B()
+        if (kn == 2 * nch) PP_STAMP(202)
+        epi_finish<MT, MODE>(p, eg, acc, u, dg, mk, bzm, scm, cur_img, mb * MB, l31, half);
+        if (kn == 2 * nch) PP_STAMP(203)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-      }
-      if (kn < K) {
-        if (cn == 0) { cur_img = st_img; cur_y0 = st_y0; }
+        cur_img = st_img; cur_y0 = st_y0;
+      } else if (kn < K && !(FDET_PP_ABL & 8)) {
         PP_WRITE_B()
       }
+      // LAST in the segment: while an LDS-DMA is in flight hipcc turns every wait for an ordinary load into vmcnt(0), which
+      // would expose the DMA's ~2 us flight inside this segment (measured: +4.4 k cycles)
+      if (grp == 1 && kn + 1 < K0 && !(FDET_PP_ABL & 8)) PP_DMA_W(kn + 1)   // panel of segment kn+1 (phases 2kn+2, 2kn+3)
     }
+    PP_STAMP(3 + 2 * ph)
     __syncthreads();
   }
 }
@@ -483,6 +634,8 @@ int launch_pp(const PpArgs& p, int VW, size_t lds, dim3 grid, hipStream_t st) {
   return check_launch("fdet_conv3x3_bf16x3(pp)");
 }
 
+long long* g_pp_stamps = nullptr;    // set only by the diagnostic build's fdet_pp_probe_set
+
 int pp_num_cus() {
   static int ncu = 0;
   if (ncu == 0) {
@@ -497,9 +650,15 @@ int pp_num_cus() {
 // Returns 1 when this kernel has no tiling / epilogue for the request (the caller then uses the round-1 kernels),
 // else the launch status.  `a` arrives with N/Cin/Cout/H/W, pointers, dgrad, slope set; `q` all null for plain modes.
 int fdet_x3_pp_run(ConvArgs a, PoolArgs q, hipStream_t st) {
-  static const bool disabled = [] { const char* e = getenv("FDET_CONV_PP"); return e && e[0] == '0'; }();
+  // Plain epilogue modes: measured on MI355X (r02, 256 x 64 x 60x60) this kernel ties or trails the round-1 small-tile kernel
+  // (fwd 0.229 vs 0.208 ms, dgrad 0.280 vs 0.237 ms): its whole epilogue (128 KB of HBM traffic per tile) falls into ONE
+  // phase, ~10 k cycles at a CU's share of HBM bandwidth against a 3.5 k cycle MFMA segment, while two free-running
+  // workgroups per CU spread it.  It is therefore opt-in for them (FDET_CONV_PP=1) and the default only for the pooled modes,
+  // which only it implements.
+  static const bool enabled = [] { const char* e = getenv("FDET_CONV_PP"); return e && e[0] == '1'; }();
   const bool pooled = q.pool_out || q.pool_din;
-  if (disabled && !pooled) return 1;
+  if (!enabled && !pooled) return 1;
+  if (!(a.slope >= 0.f && a.slope <= 1.f)) return pooled ? fail(FDET_EINVAL, "conv3x3 pooled epilogue: LeakyReLU slope must be in [0,1] (slope=%f)", (double)a.slope) : 1;
   if (a.W > 63 || a.Cout % 32 != 0 || a.Cin % 16 != 0) return pooled ? fail(FDET_EINVAL, "conv3x3 pooled epilogue: needs W <= 63, Cout %% 32 == 0 (W=%d Cout=%d)", a.W, a.Cout) : 1;
   a.WP = (a.W + 1 + 3) / 4 * 4;           // pitch % 4 == 0: a quad of positions never straddles two rows
   if (pooled) a.WP = a.W <= 31 ? 32 : 64; // whole 2x2 windows per wave need the row-pair mapping (pitch 32 or 64)
@@ -544,8 +703,13 @@ int fdet_x3_pp_run(ConvArgs a, PoolArgs q, hipStream_t st) {
   const size_t units = (size_t)(a.Cin / 16) * 9 * 2 * a.CoP;       // per hi / lo half
   p.a_hi = reinterpret_cast<const bf16x8*>(a.wpk);
   p.a_lo = p.a_hi + units;
-  a.VR = 0; a.nbands = p.bpi; a.magic_h1 = 0; a.stagger = 0;
+  a.VR = 0; a.nbands = p.bpi; a.magic_h1 = 0;
+  // start stagger: one eighth of a tile-pair period (2 * Cin/16 phases of ~3.7 k cycles) per step; only worth it when
+  // the run is long enough to amortise the late starters (FDET_PP_STAGGER=<cycles per step> overrides, 0 disables)
+  static const int stagger_env = [] { const char* e = getenv("FDET_PP_STAGGER"); return e ? atoi(e) : -1; }();
+  a.stagger = stagger_env >= 0 ? stagger_env : ((p.ntiles_mb * p.ncob >= 8 * pp_num_cus()) ? (2 * (a.Cin / 16) * 3700) / 8 : 0);
   p.c = a;
+  p.stamps = g_pp_stamps;
   const size_t lds = (size_t)(4 * 9 * 2 * MT * 32 + 8 * p.PT) * 16;
   if (lds > 160 * 1024) return pooled ? fail(FDET_EINVAL, "conv3x3 pooled epilogue: LDS") : 1;
   // one workgroup per CU, each with >= 2 tiles where the problem has them; a multiple of ncob (and of 8 when possible)
@@ -634,3 +798,14 @@ extern "C" int fdet_pool_route_bwd(const float* dout, const unsigned char* mask,
   }
   return check_launch("fdet_pool_route_bwd");
 }
+
+#ifdef FDET_PP_STAMPS
+extern "C" int fdet_pp_probe_set(long long* buf) { g_pp_stamps = buf; return 0; }
+extern "C" int fdet_pp_probe_conv(const float* x, const void* wpk, const float* bias, float* y, const float* act, int N, int C,
+                                  int H, int W, int dgrad, void* stream) {
+  ConvArgs a{};
+  a.x = x; a.wpk = (const float*)wpk; a.bias = dgrad ? nullptr : bias; a.y_full = y; a.act = dgrad ? act : nullptr;
+  a.N = N; a.Cin = C; a.Cout = C; a.H = H; a.W = W; a.dgrad = dgrad; a.slope = 0.2f;
+  return fdet_x3_pp_run(a, PoolArgs{nullptr, nullptr, nullptr, nullptr}, (hipStream_t)stream);
+}
+#endif
