@@ -60,6 +60,8 @@ int fdet_x3_pp_run(fdet::ConvArgs a, fdet::PoolArgs q, hipStream_t st);
 
 // small-tile single-buffer variant (fdet_conv3x3_x3_sb.hip); returns 1 when it has no tiling
 int fdet_x3_sb_run(fdet::ConvArgs a, hipStream_t st);
+// ... its aligned-band variant with the pooled-block epilogues
+int fdet_x3_sb_pool_run(fdet::ConvArgs a, fdet::PoolArgs q, hipStream_t st);
 
 // one translation unit per epilogue mode (fdet_conv3x3_x3_m<MODE>.hip): picks the kernel
 // instantiation for (MT, NW, NT, VW, seg) and launches it

@@ -265,6 +265,16 @@ extern "C" int fdet_conv3x3_fwd_bf16x3(const float* x, const void* wpk, const fl
   return run_x3(a, (hipStream_t)stream);
 }
 
+// pooled-block modes: aligned-band small-tile kernel (two workgroups per CU), or the ping-pong kernel (FDET_POOL_KERNEL=pp)
+static int run_x3_pooled(const ConvArgs& a, const PoolArgs& q, hipStream_t st) {
+  static const bool use_pp = [] { const char* e = getenv("FDET_POOL_KERNEL"); return e && e[0] == 'p'; }();
+  if (!use_pp) {
+    const int rc = fdet_x3_sb_pool_run(a, q, st);
+    if (rc != 1) return rc;
+  }
+  return fdet_x3_pp_run(a, q, st);
+}
+
 extern "C" int fdet_conv3x3_fwd_pool_bf16x3(const float* x, const void* wpk, const float* bias, const float* skip,
                                             const float* drop_scale, float* out_pooled, unsigned char* route, int N,
                                             int Cin, int Cout, int H, int W, float slope, void* stream) {
@@ -275,7 +285,7 @@ extern "C" int fdet_conv3x3_fwd_pool_bf16x3(const float* x, const void* wpk, con
   ConvArgs a{};
   a.x = x; a.wpk = (const float*)wpk; a.bias = bias; a.y_full = nullptr; a.skip = skip; a.scale = drop_scale;
   a.y_out = nullptr; a.act = nullptr; a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.dgrad = 0; a.slope = slope;
-  const int rc = fdet_x3_pp_run(a, PoolArgs{out_pooled, route, nullptr, nullptr}, (hipStream_t)stream);
+  const int rc = run_x3_pooled(a, PoolArgs{out_pooled, route, nullptr, nullptr}, (hipStream_t)stream);
   return rc == 1 ? fail(FDET_EINVAL, "conv3x3_fwd_pool_bf16x3: no tiling for H=%d W=%d", H, W) : rc;
 }
 
@@ -288,7 +298,7 @@ extern "C" int fdet_conv3x3_dgrad_unpool_bf16x3(const float* dz, const void* wpk
   ConvArgs a{};
   a.x = dz; a.wpk = (const float*)wpk; a.bias = nullptr; a.y_full = dx; a.skip = nullptr; a.scale = nullptr; a.y_out = nullptr;
   a.act = nullptr; a.N = N; a.Cin = Cout; a.Cout = Cin; a.H = H; a.W = W; a.dgrad = 1; a.slope = slope;
-  const int rc = fdet_x3_pp_run(a, PoolArgs{nullptr, nullptr, dout_pooled, route}, (hipStream_t)stream);
+  const int rc = run_x3_pooled(a, PoolArgs{nullptr, nullptr, dout_pooled, route}, (hipStream_t)stream);
   return rc == 1 ? fail(FDET_EINVAL, "conv3x3_dgrad_unpool_bf16x3: no tiling for H=%d W=%d", H, W) : rc;
 }
 

@@ -10,7 +10,8 @@
 // terms): ablation gave MFMA loop alone 0.18, + staging jobs and loads +0.085, + epilogue +0.055 -- every
 // part ADDS even when woven (the LDS store path and the wave's single issue stream are shared with the
 // fragment reads), and only a second co-resident workgroup overlaps the epilogue.
-#include "fdet_conv_common.h"
+#include "fdet_conv3x3_x3.h"
+#include "fdet_conv3x3_x3_epi.h"
 #include <algorithm>
 #include <cstdint>
 
@@ -18,10 +19,8 @@ using namespace fdet;
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int CK16 = 16;     // input channels per chunk (= MFMA K)
 // B staging slots per thread (8 loads of VW floats each): 2*(R+2)*(W/VW) <= nbs*NTHR is checked on the host
-__host__ __device__ constexpr int nbs_of(int nt, int vw) { return vw == 4 ? 1 : (vw == 2 ? 2 : 3); }
+__host__ __device__ constexpr int nbs_sb(int nt, int vw) { return vw == 4 ? 1 : (vw == 2 ? 2 : 3); }
 
 struct X3SbArgs {
   int ntiles, ncob;            // persistent: tiles = nbands * ncob, walked with stride gridDim.x
@@ -31,16 +30,12 @@ struct X3SbArgs {
   int PT;                    // positions per B array (cap + 2*WP + 3)
   int p_in;                  // (R+2)*W staged positions per k-half
   unsigned magic_w;
+  // aligned-band variant (AL): tiles are (image, band of R rows), a wave owns two rows x 32 columns
+  PoolArgs q;
+  unsigned magic_wp;
+  int bpi;                   // bands per image
+  unsigned magic_bpi;
 };
-
-__device__ __forceinline__ void split8(const float (&f)[8], bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)f[j];
-    hi[j] = h;
-    lo[j] = (__bf16)(f[j] - (float)h);
-  }
-}
 
 // Single LDS buffer (<= 80 KB, <= 256 registers): two workgroups share a CU, and one's staging /
 // epilogue runs beside the other's MFMAs.
@@ -156,10 +151,13 @@ __device__ __forceinline__ void epilogue_sb(const ConvArgs& a, f32x16 (&acc)[MT]
   }
 }
 
-template <int MT, int NT, int VW, int MODE>
+// AL (aligned bands): tiles are bands of R rows of ONE image (halo rows outside the image are zeros, no separator rows),
+// a wave owns two adjacent rows x 32 columns (NT == 2), and the epilogue is the shared one of fdet_conv3x3_x3_epi.h,
+// which holds whole 2x2 pooling windows per lane: the pooled-block modes EPI_FWD_POOL / EPI_DGRAD_ADDPOOL.
+template <int MT, int NT, int VW, int MODE, bool AL = false>
 __global__ void __launch_bounds__(NTHR, 2)
 k_conv3x3_x3_sb(const X3SbArgs p) {
-  constexpr int NBS = nbs_of(NT, VW);
+  constexpr int NBS = nbs_sb(NT, VW);
   using VT = typename Vec<VW>::T;
   const ConvArgs& a = p.c;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -183,7 +181,16 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     if (tile >= tend) tile = tend = p.ntiles;          // no tile for this workgroup
   }
   int mb = tile % p.ncob;
-  int v0 = (tile / p.ncob) * a.R;
+  int v0 = (tile / p.ncob) * a.R;                     // AL: (image, first row) of the band, see X3_TILE_POS
+  int t_img = 0;
+#define X3_TILE_POS(T)                                                                             \
+  {                                                                                                \
+    mb = (T) % p.ncob;                                                                             \
+    const int bt_ = (T) / p.ncob;                                                                  \
+    if (AL) { t_img = fdiv(bt_, p.magic_bpi); v0 = (bt_ - t_img * p.bpi) * a.R; }                  \
+    else v0 = bt_ * a.R;                                                                           \
+  }
+  if (tile < tend) X3_TILE_POS(tile)
   const int H1 = a.H + 1;
   const size_t HW = (size_t)a.H * a.W;
 
@@ -213,9 +220,14 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
   {                                                                                                \
     _Pragma("unroll") for (int s_ = 0; s_ < NBS; ++s_) {                                           \
       const int v_ = (V0) - 1 + b_tr[s_];                                                          \
-      const int n_ = fdiv(max(v_, 0), a.magic_h1), yy_ = v_ - n_ * H1 - 1;                         \
-      const bool ok_ = b_tr[s_] >= 0 && v_ >= 0 && v_ < a.VR && yy_ >= 0;                          \
-      b_src[s_] = ok_ ? (n_ * a.Cin * a.H + yy_) * a.W + b_xo[s_] : -1;                            \
+      if (AL) {                                                                                    \
+        const bool ok_ = b_tr[s_] >= 0 && v_ >= 0 && v_ < a.H;                                     \
+        b_src[s_] = ok_ ? (t_img * a.Cin * a.H + v_) * a.W + b_xo[s_] : -1;                        \
+      } else {                                                                                     \
+        const int n_ = fdiv(max(v_, 0), a.magic_h1), yy_ = v_ - n_ * H1 - 1;                       \
+        const bool ok_ = b_tr[s_] >= 0 && v_ >= 0 && v_ < a.VR && yy_ >= 0;                        \
+        b_src[s_] = ok_ ? (n_ * a.Cin * a.H + yy_) * a.W + b_xo[s_] : -1;                          \
+      }                                                                                            \
     }                                                                                              \
   }
   X3_TILE_SRC(v0)
@@ -272,9 +284,11 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) tapoff[t] = (t / 3) * WP + (t % 3);
 
-  const int qwave = wid * NT * 32;
+  const int wpr = WP >> 5;                                     // AL: waves per row pair (WP is 32 or 64)
+  const int qwave = AL ? ((wid / wpr) * 2 * WP + (wid - (wid / wpr) * wpr) * 32) : wid * NT * 32;
+  const int nstride = AL ? WP : 32;                            // AL: n = 0,1 are the same columns of two adjacent rows
   const int a_off = half * MB + l31;                           // + tap*2*MB + m*32 ; lo: + A_UNITS
-  const int b_off = 2 * A_UNITS + half * PT + qwave + l31;     // + tapoff + n*32   ; lo: + 2*PT
+  const int b_off = 2 * A_UNITS + half * PT + qwave + l31;     // + tapoff + n*nstride ; lo: + 2*PT
 
   X3_ISSUE_LOADS(0)
   __syncthreads();                       // zero fill complete
@@ -282,7 +296,7 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
   const int nch = a.Cin / CK16;
   bool first = true;
   for (; tile < tend; tile += tstep) {
-  const int cur_v0 = v0, cur_mb = mb;    // the tile whose chunks are consumed below
+  const int cur_v0 = v0, cur_mb = mb, cur_img = t_img;    // the tile whose chunks are consumed below
   for (int c = 0; c < nch; ++c) {
     const bf16x8* buf = lds;
     if (!first) __syncthreads();         // every wave is done reading the previous chunk
@@ -294,8 +308,7 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
     } else if (tile + tstep < tend) {
       // the next tile's first chunk travels during this tile's last MFMA block and its epilogue
       const int nt_ = tile + tstep;
-      mb = nt_ % p.ncob;
-      v0 = (nt_ / p.ncob) * a.R;
+      X3_TILE_POS(nt_)
       X3_TILE_SRC(v0)
       X3_ISSUE_LOADS(0)
     }
@@ -309,11 +322,11 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) ah[m] = Aw[t * 2 * MB + m * 32];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bl[n] = Bw[2 * PT + tapoff[t] + n * 32];
+      for (int n = 0; n < NT; ++n) bl[n] = Bw[2 * PT + tapoff[t] + n * nstride];
 #pragma unroll
       for (int m = 0; m < MT; ++m) al[m] = Aw[A_UNITS + t * 2 * MB + m * 32];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bh[n] = Bw[tapoff[t] + n * 32];
+      for (int n = 0; n < NT; ++n) bh[n] = Bw[tapoff[t] + n * nstride];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -333,7 +346,16 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
 
   // ---- epilogue: fast modes through the quad transpose (16-byte accesses), GENERIC through the
   //      channel-per-register epilogue shared with the fp32 kernel
-  if (MODE != EPI_GENERIC) {
+  if (AL) {
+    if constexpr (NT == 2) {
+      const EpiGeo eg = epi_geometry<MODE>(p, cur_img, cur_v0, qwave, nstride, cur_mb * MB, l31, half);
+      f32x4 u[MT][2][4];
+      float dg[MT][4][2], bzm[MT][4], scm[MT][4];
+      unsigned mk[MT][4];
+      epi_loads<MT, MODE>(p, eg, u, dg, mk, bzm, scm, cur_img, cur_mb * MB, l31, half);
+      epi_finish<MT, MODE>(p, eg, acc, u, dg, mk, bzm, scm, cur_img, cur_mb * MB, l31, half);
+    }
+  } else if (MODE != EPI_GENERIC) {
     epilogue_sb<MT, NT, MODE>(a, acc, cur_v0, qwave, cur_mb * MB, l31, half);
   } else {
     const int qlimit = a.R * WP;
@@ -363,8 +385,13 @@ k_conv3x3_x3_sb(const X3SbArgs p) {
 
 template <int MT, int NT>
 int launch_sb(const X3SbArgs& p, int VW, size_t lds, dim3 grid, hipStream_t st) {
+  int rc = FDET_OK;
   auto go = [&](auto kern) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      rc = fail(FDET_ELAUNCH, "conv3x3_bf16x3(sb): cannot reserve %zu bytes of LDS", lds);
+      return;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, st, p);
   };
 #define SB_MODES(V_)                                                                               \
@@ -378,7 +405,38 @@ int launch_sb(const X3SbArgs& p, int VW, size_t lds, dim3 grid, hipStream_t st) 
   }
   if (VW == 4) { SB_MODES(4) } else if (VW == 2) { SB_MODES(2) } else { SB_MODES(1) }
 #undef SB_MODES
+  if (rc != FDET_OK) return rc;
   return check_launch("fdet_conv3x3_bf16x3(sb)");
+}
+
+// aligned-band variant: the pooled-block modes
+template <int MT>
+int launch_sb_pool(const X3SbArgs& p, int VW, size_t lds, dim3 grid, hipStream_t st) {
+  int rc = FDET_OK;
+  auto go = [&](auto kern) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      rc = fail(FDET_ELAUNCH, "conv3x3_bf16x3(sb, pooled): cannot reserve %zu bytes of LDS", lds);
+      return;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, st, p);
+  };
+#define SB_PMODES(V_)                                                                              \
+  if (p.c.mode == EPI_FWD_POOL) go(k_conv3x3_x3_sb<MT, 2, V_, EPI_FWD_POOL, true>);               \
+  else go(k_conv3x3_x3_sb<MT, 2, V_, EPI_DGRAD_ADDPOOL, true>);
+  if (VW == 4) { SB_PMODES(4) } else if (VW == 2) { SB_PMODES(2) } else { SB_PMODES(1) }
+#undef SB_PMODES
+  if (rc != FDET_OK) return rc;
+  return check_launch("fdet_conv3x3_bf16x3(sb, pooled)");
+}
+
+int sb_num_cus() {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return ncu;
 }
 
 }  // namespace
@@ -405,8 +463,11 @@ int fdet_x3_sb_run(ConvArgs a, hipStream_t st) {
   }
   const int rows_total = a.VR - 1;
   int bestNT = 0, bestMT = 0, bestR = 0; double bestT = 0;
-  int forceMT = 0, forceNT = 0;
-  if (const char* e = getenv("FDET_SB_TILE")) sscanf(e, "%d,%d", &forceMT, &forceNT);
+  static const struct Force { int mt = 0, nt = 0, grid = -1; Force() {            // development knobs, read once
+    if (const char* e = getenv("FDET_SB_TILE")) sscanf(e, "%d,%d", &mt, &nt);
+    if (const char* e = getenv("FDET_SB_GRID")) grid = atoi(e);
+  } } force;
+  const int forceMT = force.mt, forceNT = force.nt;
   for (int MT = (a.CoP % 64 == 0) ? 2 : 1; MT >= 1; --MT)
     for (int NT = 2; NT >= 1; NT >>= 1) {
       if (forceMT && (MT != forceMT || NT != forceNT)) continue;
@@ -414,7 +475,7 @@ int fdet_x3_sb_run(ConvArgs a, hipStream_t st) {
       if (a.WP > cap) continue;
       int R = cap / a.WP;
       if (R > rows_total) R = rows_total;
-      if (2 * (R + 2) * (a.W / VW) > nbs_of(NT, VW) * NTHR) continue;
+      if (2 * (R + 2) * (a.W / VW) > nbs_sb(NT, VW) * NTHR) continue;
       const int PT = cap + 2 * a.WP + 3;
       const size_t lds = (size_t)(2 * 9 * 2 * MT * 32 + 4 * PT) * 16;
       if (lds > 80 * 1024) continue;
@@ -443,14 +504,52 @@ int fdet_x3_sb_run(ConvArgs a, hipStream_t st) {
   p.ntiles = a.nbands * p.ncob;
   // persistent: two workgroups per CU walk the tiles (the zero fill and the first-chunk latency are
   // paid once per workgroup, later tiles prefetch their first chunk under the previous tile's tail)
-  int ncu = 256;
-  { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v; }
-  int gsz = 2 * ncu;
-  if (const char* e = getenv("FDET_SB_GRID")) gsz = atoi(e) > 0 ? atoi(e) : p.ntiles;
+  int gsz = 2 * sb_num_cus();
+  if (force.grid >= 0) gsz = force.grid > 0 ? force.grid : p.ntiles;
   dim3 grid(p.ntiles < gsz ? p.ntiles : gsz, 1);
   p.c.stagger = 0;
   if (MT == 2 && NT == 2) return launch_sb<2, 2>(p, VW, lds, grid, st);
   if (MT == 2 && NT == 1) return launch_sb<2, 1>(p, VW, lds, grid, st);
   if (MT == 1 && NT == 2) return launch_sb<1, 2>(p, VW, lds, grid, st);
   return launch_sb<1, 1>(p, VW, lds, grid, st);
+}
+
+// Pooled-block modes on the aligned-band variant (two workgroups per CU).  Returns 1 when it has no tiling.
+int fdet_x3_sb_pool_run(ConvArgs a, PoolArgs q, hipStream_t st) {
+  if (!(a.slope >= 0.f && a.slope <= 1.f) || a.W > 62 || (a.W & 1) || (a.H & 1) || a.Cout % 32 != 0 || a.Cin % 16 != 0) return 1;
+  a.WP = a.W <= 31 ? 32 : 64;             // whole 2x2 windows per wave: row pitch 32 or 64
+  auto aligned = [](const void* ptr, size_t b) { return ((uintptr_t)ptr % b) == 0; };
+  const int VW = (a.W % 4 == 0 && aligned(a.x, 16)) ? 4 : (aligned(a.x, 8) ? 2 : 1);
+  if ((size_t)a.N * std::max(a.Cin, a.Cout) * a.H * a.W >= (size_t)1 << 31) return 1;
+  a.CoP = a.Cout;
+  if (q.pool_out && !a.dgrad && a.bias && a.skip && !a.y_full && !a.y_out) a.mode = EPI_FWD_POOL;
+  else if (q.pool_din && q.mask_in && a.dgrad && !a.act && !a.skip && a.y_full) a.mode = EPI_DGRAD_ADDPOOL;
+  else return 1;
+  const int MT = (a.CoP % 64 == 0) ? 2 : 1, cap = 256;
+  int R = cap / a.WP;
+  if (R > a.H) R = a.H;                   // H is even
+  if (2 * (R + 2) * (a.W / VW) > nbs_sb(2, VW) * NTHR) return 1;
+  a.R = R;
+  X3SbArgs p;
+  p.q = q;
+  p.PT = cap + 2 * a.WP + 3;
+  p.p_in = (a.R + 2) * (a.W / VW);
+  p.magic_w = magic_of(a.W / VW);
+  p.magic_wp = magic_of(a.WP);
+  p.bpi = (a.H + a.R - 1) / a.R;
+  p.magic_bpi = magic_of(p.bpi);
+  const long nbt = (long)a.N * p.bpi;
+  if (nbt >= (1 << 20)) return 1;
+  const size_t units = (size_t)(a.Cin / 16) * 9 * 2 * a.CoP;
+  p.a_hi = reinterpret_cast<const bf16x8*>(a.wpk);
+  p.a_lo = p.a_hi + units;
+  a.VR = 0; a.nbands = (int)nbt; a.magic_h1 = 0; a.stagger = 0;
+  p.c = a;
+  const size_t lds = (size_t)(2 * 9 * 2 * MT * 32 + 4 * p.PT) * 16;
+  if (lds > 80 * 1024) return 1;
+  p.ncob = a.CoP / (MT * 32);
+  p.ntiles = (int)nbt * p.ncob;
+  const int gsz = 2 * sb_num_cus();
+  dim3 grid(p.ntiles < gsz ? p.ntiles : gsz, 1);
+  return MT == 2 ? launch_sb_pool<2>(p, VW, lds, grid, st) : launch_sb_pool<1>(p, VW, lds, grid, st);
 }
