@@ -74,6 +74,14 @@ int run_x3(ConvArgs a, hipStream_t st) {
         const int rc = fdet_x3_pp_run(a, PoolArgs{nullptr, nullptr, nullptr, nullptr}, st);
         if (rc != 1) return rc;
       }
+      // aligned-band variant of the small-tile kernel (no separator rows, shared epilogue with two-instruction quad
+      // exchanges): measured -6 % / -7 % on the 60x60 forward / data-gradient launches, a wash at 30x30 (bands of 8 rows
+      // cover 32 of 30): default for rows of 33..63 columns; FDET_SB_AL=0 / 1 forces it off / on for every width
+      static const int sb_al = [] { const char* e = getenv("FDET_SB_AL"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+      if (sb_al == 1 || (sb_al < 0 && a.W >= 33)) {
+        const int rc = fdet_x3_sb_pool_run(a, PoolArgs{nullptr, nullptr, nullptr, nullptr}, st);
+        if (rc != 1) return rc;
+      }
       const int rc = fdet_x3_sb_run(a, st);
       if (rc != 1) return rc;
     }

@@ -422,8 +422,15 @@ int launch_sb_pool(const X3SbArgs& p, int VW, size_t lds, dim3 grid, hipStream_t
     hipLaunchKernelGGL(kern, grid, dim3(NTHR), lds, st, p);
   };
 #define SB_PMODES(V_)                                                                              \
-  if (p.c.mode == EPI_FWD_POOL) go(k_conv3x3_x3_sb<MT, 2, V_, EPI_FWD_POOL, true>);               \
-  else go(k_conv3x3_x3_sb<MT, 2, V_, EPI_DGRAD_ADDPOOL, true>);
+  switch (p.c.mode) {                                                                              \
+    case EPI_FWD_POOL: go(k_conv3x3_x3_sb<MT, 2, V_, EPI_FWD_POOL, true>); break;                  \
+    case EPI_DGRAD_ADDPOOL: go(k_conv3x3_x3_sb<MT, 2, V_, EPI_DGRAD_ADDPOOL, true>); break;        \
+    case EPI_FWD_FULL: go(k_conv3x3_x3_sb<MT, 2, V_, EPI_FWD_FULL, true>); break;                  \
+    case EPI_FWD_BOTH: go(k_conv3x3_x3_sb<MT, 2, V_, EPI_FWD_BOTH, true>); break;                  \
+    case EPI_FWD_OUT: go(k_conv3x3_x3_sb<MT, 2, V_, EPI_FWD_OUT, true>); break;                    \
+    case EPI_DGRAD_ACT: go(k_conv3x3_x3_sb<MT, 2, V_, EPI_DGRAD_ACT, true>); break;                \
+    default: go(k_conv3x3_x3_sb<MT, 2, V_, EPI_DGRAD_ADD, true>); break;                           \
+  }
   if (VW == 4) { SB_PMODES(4) } else if (VW == 2) { SB_PMODES(2) } else { SB_PMODES(1) }
 #undef SB_PMODES
   if (rc != FDET_OK) return rc;
@@ -516,18 +523,32 @@ int fdet_x3_sb_run(ConvArgs a, hipStream_t st) {
 
 // Pooled-block modes on the aligned-band variant (two workgroups per CU).  Returns 1 when it has no tiling.
 int fdet_x3_sb_pool_run(ConvArgs a, PoolArgs q, hipStream_t st) {
-  if (!(a.slope >= 0.f && a.slope <= 1.f) || a.W > 62 || (a.W & 1) || (a.H & 1) || a.Cout % 32 != 0 || a.Cin % 16 != 0) return 1;
-  a.WP = a.W <= 31 ? 32 : 64;             // whole 2x2 windows per wave: row pitch 32 or 64
+  const bool pooled_ = q.pool_out || q.pool_din;
+  if (!(a.slope >= 0.f && a.slope <= 1.f) || a.W > 63 || a.Cout % 32 != 0 || a.Cin % 16 != 0) return 1;
+  if (pooled_ && (a.W > 62 || (a.W & 1) || (a.H & 1))) return 1;
+  if (!pooled_ && a.W < 17) return 1;     // narrow plain maps: the 64-positions-per-wave mapping wastes fewer lanes
+  a.WP = a.W <= 31 ? 32 : 64;             // a wave owns two rows x 32 columns: row pitch 32 or 64
   auto aligned = [](const void* ptr, size_t b) { return ((uintptr_t)ptr % b) == 0; };
   const int VW = (a.W % 4 == 0 && aligned(a.x, 16)) ? 4 : (aligned(a.x, 8) ? 2 : 1);
   if ((size_t)a.N * std::max(a.Cin, a.Cout) * a.H * a.W >= (size_t)1 << 31) return 1;
   a.CoP = a.Cout;
-  if (q.pool_out && !a.dgrad && a.bias && a.skip && !a.y_full && !a.y_out) a.mode = EPI_FWD_POOL;
-  else if (q.pool_din && q.mask_in && a.dgrad && !a.act && !a.skip && a.y_full) a.mode = EPI_DGRAD_ADDPOOL;
-  else return 1;
+  const bool pooled = q.pool_out || q.pool_din;
+  a.mode = -1;
+  if (pooled) {
+    if (q.pool_out && !a.dgrad && a.bias && a.skip && !a.y_full && !a.y_out) a.mode = EPI_FWD_POOL;
+    else if (q.pool_din && q.mask_in && a.dgrad && !a.act && !a.skip && a.y_full) a.mode = EPI_DGRAD_ADDPOOL;
+  } else if (!a.dgrad && a.bias) {
+    if (a.y_full && !a.y_out) a.mode = EPI_FWD_FULL;
+    else if (a.y_full && a.y_out && a.skip && a.scale) a.mode = EPI_FWD_BOTH;
+    else if (!a.y_full && a.y_out && a.skip && !a.scale) a.mode = EPI_FWD_OUT;
+  } else if (a.dgrad) {
+    if (a.act && !a.skip) a.mode = EPI_DGRAD_ACT;
+    else if (!a.act && a.skip) a.mode = EPI_DGRAD_ADD;
+  }
+  if (a.mode < 0) return 1;
   const int MT = (a.CoP % 64 == 0) ? 2 : 1, cap = 256;
   int R = cap / a.WP;
-  if (R > a.H) R = a.H;                   // H is even
+  if (R > a.H) R = (a.H + 1) & ~1;        // row pairs
   if (2 * (R + 2) * (a.W / VW) > nbs_sb(2, VW) * NTHR) return 1;
   a.R = R;
   X3SbArgs p;
