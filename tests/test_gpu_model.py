@@ -106,9 +106,11 @@ def test_fused_train_steps_vs_oracle(fd, kind, F, size, S, nb, B):
         # start from parameters 2e-4 apart; the loss' 1/sqrt(p) terms amplify that: 2e-3 there.
         # The engine runs these channel counts in bf16x3 arithmetic (~1e-5 of fp32): forward and
         # loss stay within 1e-4 (asserted above).  The GRADIENT is a discontinuous function of the
-        # activations (2x2 max-pool argmax routing in blocks 0-1): perturbing the fp32 oracle's own
-        # weights by 1e-5 relative already moves single gradient entries by 1e-2 of the tensor's
-        # scale.  So gradients are compared in the L2 sense, with a loose bound on single entries.
+        # activations (2x2 max-pool routing, LeakyReLU kinks): one tied window or one activation at a kink
+        # that rounds the other way moves single entries by 1e-3..1e-2 of the tensor's scale -- in the
+        # exact-fp32 arithmetic too.  test_gradient_entries_differ_only_through_pool_routing proves that
+        # this is the ONLY source (per-entry 1e-4 once the oracle's decisions are injected); here, with
+        # the kernel's own decisions, gradients are compared in the L2 sense with a loose per-entry bound.
         for i, n in enumerate(names):
             got = sp.view(sp.grad, i).detach().cpu().double()
             ref = G_ref[n].double()
@@ -241,3 +243,245 @@ def test_graphed_predict_equals_eager(fd):
         assert got.shape == eager.shape and torch.equal(got.cpu(), eager.cpu())
         both = gp(f)
         assert len(both) == 2 and torch.equal(both[0].cpu(), eager.cpu())
+
+
+def _redraw_u8(B, size, seed, checksum):
+    x_u8 = torch.randint(0, 256, (B, 3, size, size), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
+    assert int(x_u8.long().sum()) == int(checksum)
+    return x_u8
+
+
+def test_reference_modelmeta_two_steps_lightning_path(fd, golden):
+    """g11 = the REFERENCE's ModelMeta.training_step + loss.backward() + SAMSGD.step(), twice (tools/make_goldens_r2.py).
+    The mirror goes the same way (training_step -> loss.backward() -> optimizer.step()): loss, metric block and the
+    parameters after each step against the reference's.  Q18 (the SAM wrapper's w+e-e rounding, <= 7.5e-9 in the fixture)
+    is below the comparison's resolution."""
+    from fdet_amd.models import ModelMeta
+    g = golden("g11_modelmeta_F8")
+    B, steps, seed = int(g["B"]), int(g["steps"]), int(g["seed"])
+    P0 = {k[len("param0/"):]: v for k, v in g.items() if k.startswith("param0/")}
+    model = _load(_build(fd, "poolresnet", 8, 480, 10, 10), P0).train()
+    mm = ModelMeta(model=model, lr=1e-4)
+    (opt,), _ = mm.configure_optimizers()
+    for st in range(1, steps + 1):
+        x = (_redraw_u8(B, 480, seed + st, g[f"x_checksum/{st}"]).float() / 255.0).cuda()
+        y = g[f"y/{st}"].cuda()
+        boxes = [g[f"boxes/{st}/{i}"] for i in range(B)]
+        model.set_dropout_masks({k[len(f"mask/{st}/"):]: v for k, v in g.items() if k.startswith(f"mask/{st}/")})
+        out = mm.training_step((x, y, boxes), 1)
+        assert abs(float(out["loss"]) - float(g[f"loss/{st}"])) <= 1e-4 * float(g[f"loss/{st}"])
+        m = g[f"metrics/{st}"]
+        assert abs(float(out["total_iou"]) - float(m[0])) <= 1e-4 * max(1.0, float(m[0]))
+        assert abs(float(out["total_recall"]) - float(m[1])) <= 1e-6 and abs(float(out["total_precision"]) - float(m[2])) <= 1e-6
+        opt.zero_grad()
+        out["loss"].backward()
+        for n, p in model.named_parameters():
+            rel_close(p.grad, g[f"grad/{st}/{n}"], 1e-4 if st == 1 else 2e-3)   # step 2 starts ~lr*sign-noise apart
+        opt.step()
+        for n, p in model.named_parameters():
+            d = (p.detach().cpu() - g[f"param/{st}/{n}"]).abs()
+            assert float(d.max()) <= 2.1e-4 * st, (st, n)
+            assert float((d > 1e-6).float().mean()) < 0.02, (st, n)
+
+
+def test_reference_f16_train_step_reaches_bf16x3_backward(fd, golden):
+    """g12 = one reference train step of PoolResnet(filters=16): the reference-generated fixture that runs through
+    the bf16x3 forward, data-gradient and weight-gradient kernels (16 channels is their narrowest width), the pooled
+    blocks' fused epilogues included."""
+    from fdet_amd.models import ModelMeta
+    g = golden("g12_poolresnet_F16")
+    P = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    model = _load(_build(fd, "poolresnet", 16, 480, 10, 10), P).train()
+    assert model.engine.x3
+    mm = ModelMeta(model=model, lr=1e-4)
+    mm.configure_optimizers()
+    x = (_redraw_u8(int(g["B"]), 480, int(g["seed"]), g["x_checksum"]).float() / 255.0).cuda()
+    model.set_dropout_masks({k[len("mask/"):]: v for k, v in g.items() if k.startswith("mask/")})
+    lsum, y_hat, _ = mm.fused_train_step(x, g["y"].cuda())
+    assert torch.allclose(y_hat.cpu(), g["y_train"], atol=1e-4)
+    assert abs(float(lsum) - float(g["loss"])) <= 1e-4 * max(1.0, float(g["loss"]))
+    sp = mm.opt.space
+    names, _ = model.named_stack_params()
+    for i, n in enumerate(names):
+        got = sp.view(sp.grad, i).detach().cpu().double()
+        ref = g["grad/" + n].double()
+        rel_l2 = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert rel_l2 <= 2e-3, (n, rel_l2)
+        rel_close(got, ref, 2e-2)                     # single entries: max-pool routing of near-tied windows, see
+        #                                               test_gradient_entries_differ_only_through_pool_routing
+    for n, p in model.named_parameters():
+        d = (p.detach().cpu() - g["param_after/" + n]).abs()
+        assert float(d.max()) <= 2.1e-4, n
+        assert float((d > 1e-6).float().mean()) < 0.02, n
+
+
+def _oracle_blocks(spec, P, x, masks):
+    """The oracle's forward (oracle.model_forward's own ops) with every block's intermediates kept:
+    k -> (c, e, a, block input, pooled?)."""
+    import torch.nn.functional as F
+    S = spec.num_of_patches
+    h = F.conv2d(x, P["conv1.weight"], P["conv1.bias"], stride=spec.stem_s, padding=spec.stem_p)
+    keep = {}
+    for k in range(spec.num_blocks):
+        skip = h
+        a = F.leaky_relu(F.conv2d(h, P[f"residual_blocks.{k}.conv1.weight"], P[f"residual_blocks.{k}.conv1.bias"], padding=1), 0.2)
+        c = F.leaky_relu(F.conv2d(a, P[f"residual_blocks.{k}.conv2.weight"], P[f"residual_blocks.{k}.conv2.bias"], padding=1), 0.2)
+        e = c * masks[f"residual_blocks.{k}"][:, :, None, None] + skip
+        h = e
+        pooled = h.shape[2] > spec.pool_mult * S
+        keep[k] = (c, e, a, skip, pooled)
+        if pooled:
+            h = F.max_pool2d(h, 2)
+    return keep
+
+
+def _route_bytes(c, e):
+    """Routing bytes (include/fdet.h: bits 0-3 c > 0 per window element in scan order, bits 4-5 argmax, first
+    maximum wins) from fp32 CPU tensors, and the gap between each window's two largest entries."""
+    N, C, H, W = e.shape
+    ew = e.unfold(2, 2, 2).unfold(3, 2, 2).reshape(N, C, H // 2, W // 2, 4)
+    cw = c.unfold(2, 2, 2).unfold(3, 2, 2).reshape(N, C, H // 2, W // 2, 4)
+    arg = ew.argmax(dim=-1)                                   # first maximum (torch CPU argmax returns the first)
+    bits = sum(((cw[..., k] > 0).long() << k) for k in range(4))
+    top2 = ew.topk(2, dim=-1).values
+    return (bits | (arg << 4)).to(torch.uint8), top2[..., 0] - top2[..., 1]
+
+
+def test_gradient_entries_differ_only_through_pool_routing(fd):
+    """at F=64 in the benchmarked bf16x3 arithmetic single gradient entries sit up to 5e-2 of the
+    tensor scale away from the fp32 oracle while forward and loss hold 1e-4.  The claim was that only the 2x2 max-pool
+    routing (a discontinuous function of the activations) does this.  Proof on the product kernels:
+      (1) the routing bytes written by the fused forward differ from the oracle's ONLY in windows whose two largest
+          entries are within rounding of each other, and the saved conv1 activations differ in SIGN (the LeakyReLU kink,
+          the other discontinuity of the backward pass) only where they are within rounding of zero;
+      (2) with the oracle's decisions (routing bytes; a and c of every block, which differ from the kernel's by rounding
+          only) put in place of the kernel's, EVERY parameter-gradient entry is within 1e-4 of its tensor's scale of the
+          oracle's autograd -- per entry, the north star's tolerance (measured: <= 1e-5; with the kernel's own decisions
+          up to 4.5e-3, caused by ONE window and a handful of activations at a kink)."""
+    from fdet_amd import hotpath as hp
+    F_, size, S, B = 64, 480, 10, 3
+    spec = O.poolresnet_spec(F_, (3, size, size), S)
+    P = O.init_params(spec, seed=3)
+    model = _load(_build(fd, "poolresnet", F_, size, S, 10), P).train()
+    eng = model.engine
+    assert eng.x3 and eng.pool_fusion
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(11))
+    y = torch.stack([O.encode_targets(b, (size, size), S) for b in O.synthetic_boxes(B, size, seed=1)])
+    masks = O.make_dropout_masks(spec, B, seed=101)
+    # oracle: gradients by autograd, pooled-block intermediates by the same ops
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss_ref = O.batch_loss(O.model_forward(spec, leaves, x, masks), y)
+    G_ref = dict(zip(leaves, torch.autograd.grad(loss_ref, list(leaves.values()))))
+    with torch.no_grad():
+        inter = _oracle_blocks(spec, P, x, masks)
+    assert [k for k in inter if inter[k][4]] == [0, 1]
+    names, params = model.named_stack_params()
+    Pd = {n: p.data for n, p in zip(names, params)}
+    md = {k: v.cuda() for k, v in masks.items()}
+
+    def run(replace_routes):
+        y_hat, saved = eng.forward(x.cuda(), Pd, md, save=True)
+        _, lsum, dy = hp.yolo_loss_fwd_bwd(y_hat, y.cuda(), want_grad=True)
+        stats = {}
+        for k, (c_ref, e_ref, a_ref, xin_ref, pooled) in inter.items():
+            xin, a, third = saved["blocks"][k]
+            a_got = a.cpu()
+            # LeakyReLU kinks: elements whose SIGN the kernel and the oracle disagree on (conv1's a; conv2's c below)
+            flip_a = (a_got > 0) != (a_ref > 0)
+            worst_kink = float(a_ref[flip_a].abs().max()) / float(a_ref.abs().max()) if flip_a.any() else 0.0
+            n_flip = int(flip_a.sum())
+            assert float((a_got - a_ref).abs().max()) <= 1e-4 * float(a_ref.abs().max())
+            if pooled:
+                assert third.dtype == torch.uint8                # the fused forward kept routing bytes, not c
+                ref_bytes, gap = _route_bytes(c_ref, e_ref)
+                got = third.cpu()
+                diff_arg = ((got >> 4) != (ref_bytes >> 4))
+                n_flip += int(((got & 15) != (ref_bytes & 15)).sum())
+                stats[k] = (int(diff_arg.sum()), float(gap[diff_arg].max()) / float(e_ref.abs().max()) if diff_arg.any() else 0.0,
+                            diff_arg.numel(), n_flip, worst_kink)
+                if replace_routes:
+                    saved["blocks"][k] = (xin, a_ref.cuda(), ref_bytes.cuda())
+            else:
+                c_got = third.cpu()
+                flip_c = (c_got > 0) != (c_ref > 0)
+                if flip_c.any():
+                    worst_kink = max(worst_kink, float(c_ref[flip_c].abs().max()) / float(c_ref.abs().max()))
+                stats[k] = (0, 0.0, a_ref.numel(), n_flip + int(flip_c.sum()), worst_kink)
+                if replace_routes:
+                    saved["blocks"][k] = (xin, a_ref.cuda(), c_ref.cuda())
+        G = {n: torch.empty_like(p) for n, p in Pd.items()}
+        eng.backward(saved, dy, Pd, G)
+        return float(lsum), {n: v.cpu() for n, v in G.items()}, stats
+
+    lsum, G_own, stats = run(False)
+    assert abs(lsum - float(loss_ref)) <= 1e-4 * float(loss_ref)
+    for k, (n_arg, worst_gap, total, n_flip, worst_kink) in stats.items():
+        # (1): every window routed differently is a near-tie (gap below 1e-4 of the map's scale), every LeakyReLU input
+        # whose sign differs is within 1e-4 of zero -- and both are rare
+        assert worst_gap <= 1e-4 and worst_kink <= 1e-4, (k, worst_gap, worst_kink)
+        assert n_arg <= 2e-4 * total and n_flip <= 1e-3 * total, (k, n_arg, n_flip, total)
+    _, G_inj, _ = run(True)
+    errs = []
+    for n in names:
+        ref = G_ref[n].double()
+        scale = max(float(ref.abs().max()), 1e-3)
+        errs.append((n, float((G_own[n].double() - ref).abs().max()) / scale, float((G_inj[n].double() - ref).abs().max()) / scale))
+    print("per-entry gradient error / tensor scale (own routing, oracle routing):")
+    for n, eo, ei in errs:
+        print(f"   {n:40s} {eo:.2e} {ei:.2e}")
+    print(f"windows routed differently: { {k: v[0] for k, v in stats.items() if v[0]} }, lrelu inputs with another sign: "
+          f"{ {k: v[3] for k, v in stats.items() if v[3]} }")
+    for n, eo, ei in errs:
+        assert ei <= 1e-4, (n, ei)                           # (2): per entry, the north star's tolerance (measured <= 1e-5)
+
+
+def test_gradients_per_entry_in_exact_fp32_arithmetic(fd, monkeypatch):
+    """The same statement in the exact-fp32 MFMA arithmetic (FDET_PRECISION=f32; the separate tail kernels recompute the
+    pooling argmax from the saved fp32 tensors): even there single entries move by 1e-3 of the scale, because the kernel's
+    fmaf chains and oneDNN's differ by summation order (~1e-6) and a tied window / an activation at the LeakyReLU kink
+    flips at ANY non-zero difference.  With the oracle's saved tensors (block input, a, c of every block) in place
+    of the kernel's, every entry is within 1e-4 -- per entry, the north star's tolerance."""
+    monkeypatch.setenv("FDET_PRECISION", "f32")
+    from fdet_amd import hotpath as hp
+    F_, size, S, B = 64, 480, 10, 2
+    spec = O.poolresnet_spec(F_, (3, size, size), S)
+    P = O.init_params(spec, seed=3)
+    model = _load(_build(fd, "poolresnet", F_, size, S, 10), P).train()
+    eng = model.engine
+    assert not eng.x3
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(11))
+    y = torch.stack([O.encode_targets(b, (size, size), S) for b in O.synthetic_boxes(B, size, seed=1)])
+    masks = O.make_dropout_masks(spec, B, seed=101)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss_ref = O.batch_loss(O.model_forward(spec, leaves, x, masks), y)
+    G_ref = dict(zip(leaves, torch.autograd.grad(loss_ref, list(leaves.values()))))
+    with torch.no_grad():
+        inter = _oracle_blocks(spec, P, x, masks)
+    names, params = model.named_stack_params()
+    Pd = {n: p.data for n, p in zip(names, params)}
+
+    def run(inject):
+        y_hat, saved = eng.forward(x.cuda(), Pd, {k: v.cuda() for k, v in masks.items()}, save=True)
+        _, lsum, dy = hp.yolo_loss_fwd_bwd(y_hat, y.cuda(), want_grad=True)
+        if inject:
+            for k, (c_ref, e_ref, a_ref, xin_ref, _pooled) in inter.items():
+                xin, a, c = saved["blocks"][k]
+                for got, ref in ((xin, xin_ref), (a, a_ref), (c, c_ref)):
+                    assert float((got.cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+                saved["blocks"][k] = (xin_ref.cuda(), a_ref.cuda(), c_ref.cuda())
+        G = {n: torch.empty_like(p) for n, p in Pd.items()}
+        eng.backward(saved, dy, Pd, G)
+        return float(lsum), {n: v.cpu() for n, v in G.items()}
+
+    lsum, G_own = run(False)
+    assert abs(lsum - float(loss_ref)) <= 1e-5 * float(loss_ref)
+    _, G_inj = run(True)
+    worst_own = worst_inj = 0.0
+    for n in names:
+        ref = G_ref[n].double()
+        scale = max(float(ref.abs().max()), 1e-3)
+        worst_own = max(worst_own, float((G_own[n].double() - ref).abs().max()) / scale)
+        e_inj = float((G_inj[n].double() - ref).abs().max()) / scale
+        worst_inj = max(worst_inj, e_inj)
+        assert e_inj <= 1e-4, (n, e_inj)
+    print(f"f32 arithmetic, worst per-entry gradient error / tensor scale: own decisions {worst_own:.2e}, oracle's {worst_inj:.2e}")

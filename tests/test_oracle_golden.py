@@ -193,3 +193,58 @@ def test_adam_matches_torch_foreach():
         O.adam_step(ps, gs, m, v, step)
         for a, b in zip(ps, ref):
             assert torch.allclose(a, b.detach(), atol=1e-7, rtol=1e-6)
+
+
+def _redraw_u8(B, size, seed, checksum):
+    x_u8 = torch.randint(0, 256, (B, 3, size, size), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
+    assert int(x_u8.long().sum()) == int(checksum), "the seeded input stream differs from the one the fixture was made with"
+    return x_u8
+
+
+def test_reference_modelmeta_samsgd_and_metric_block(golden):
+    """g11 (tools/make_goldens_r2.py): the REFERENCE's ModelMeta.training_step + loss.backward() + SAMSGD.step(),
+    two iterations.  Pins the oracle's train step (a11), Adam restatement (a10) and metric block (a9) to reference
+    output, and quantifies quirk Q18: the reference's SAM wrapper differs from a plain Adam step by its w+e-e
+    rounding only."""
+    g = golden("g11_modelmeta_F8")
+    B, steps, seed = int(g["B"]), int(g["steps"]), int(g["seed"])
+    spec = O.poolresnet_spec(8, (3, 480, 480), 10)
+    P = {k[len("param0/"):]: v.clone() for k, v in g.items() if k.startswith("param0/")}
+    state = {"exp_avg": {k: torch.zeros_like(v) for k, v in P.items()},
+             "exp_avg_sq": {k: torch.zeros_like(v) for k, v in P.items()}}
+    red = O.ReduceBoundingBoxes(0.5, 0.5, (3, 480, 480), 10)
+    for st in range(1, steps + 1):
+        x = _redraw_u8(B, 480, seed + st, g[f"x_checksum/{st}"]).float() / 255.0
+        masks = {k[len(f"mask/{st}/"):]: v for k, v in g.items() if k.startswith(f"mask/{st}/")}
+        # Q18, quantified on the reference's own numbers: SAMSGD's result vs plain multi-tensor Adam on the same gradients
+        for k in P:
+            dev = float((g[f"param/{st}/{k}"] - g[f"adam_only/{st}/{k}"]).abs().max())
+            assert dev <= 2e-8, (k, dev)                     # measured: 3.7e-9 (step 1), 7.5e-9 (step 2) = w+e-e rounding
+        loss, y_hat, G = O.train_step(spec, P, state, st, x, g[f"y/{st}"], masks)
+        assert abs(float(loss) - float(g[f"loss/{st}"])) <= 1e-5 * float(g[f"loss/{st}"])
+        iou, rec, prec = O.step_metrics(y_hat, g[f"y/{st}"], red)
+        m = g[f"metrics/{st}"]
+        assert abs(iou - float(m[0])) <= 1e-5 * max(1.0, float(m[0])) and rec == float(m[1]) and prec == float(m[2])
+        for k in G:
+            ref = g[f"grad/{st}/{k}"]
+            assert torch.allclose(G[k], ref, atol=1e-5 + 1e-4 * float(ref.abs().max()), rtol=1e-4), (st, k)
+            d = (P[k] - g[f"param/{st}/{k}"]).abs()
+            assert float(d.max()) <= 2.1e-4 * st, (st, k)    # Adam: ~lr*sign(g) per step where |g| is rounding noise
+            assert float((d > 1e-6).float().mean()) < 0.02, (st, k)
+
+
+def test_reference_poolresnet_f16_train_step(golden):
+    """g12: reference PoolResnet(filters=16) train step (the narrowest width the bf16x3 kernels run)."""
+    g = golden("g12_poolresnet_F16")
+    spec = O.poolresnet_spec(16, (3, 480, 480), 10)
+    P = {k[len("param/"):]: v.clone() for k, v in g.items() if k.startswith("param/")}
+    masks = {k[len("mask/"):]: v for k, v in g.items() if k.startswith("mask/")}
+    x = _redraw_u8(int(g["B"]), 480, int(g["seed"]), g["x_checksum"]).float() / 255.0
+    state = {"exp_avg": {k: torch.zeros_like(v) for k, v in P.items()},
+             "exp_avg_sq": {k: torch.zeros_like(v) for k, v in P.items()}}
+    loss, y_train, G = O.train_step(spec, P, state, 1, x, g["y"], masks)
+    assert torch.allclose(y_train, g["y_train"], atol=1e-5, rtol=1e-5)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, float(g["loss"]))
+    for k in G:
+        ref = g["grad/" + k]
+        assert torch.allclose(G[k], ref, atol=1e-5 + 1e-4 * float(ref.abs().max()), rtol=1e-4), k
