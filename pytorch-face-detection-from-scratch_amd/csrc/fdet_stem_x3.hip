@@ -651,11 +651,11 @@ k_stem_wgrad_x3_pipe(const StemWgX3Args a) {
     __syncthreads();                                                                              \
     row += 1;                                                                                     \
   }
-  while (row < last) {
-    SWP_ROW(0)
-    if (row >= last) break;
-    SWP_ROW(1)
-  }
+  // ONE loop body, the plane-tile parity is a run-time scalar: with two unrolled bodies (parity 0 / 1) hipcc gave them
+  // different register assignments and bridged the back edge with copies of the x register set -- copies of registers
+  // whose asm loads may still be in flight (tools/audit_asm_loads.py, count-aware since round 2, flagged 56 of them;
+  // the round-1 audit's 150-line window had hidden them).  A copy taken before the data lands keeps the stale value.
+  for (int par = 0; row < last; par ^= 1) SWP_ROW(par)
   asm volatile("s_waitcnt vmcnt(0)");
   SWP_PASS_X(0) SWP_PASS_D()
 #undef SWP_ROW

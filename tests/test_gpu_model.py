@@ -485,3 +485,44 @@ def test_gradients_per_entry_in_exact_fp32_arithmetic(fd, monkeypatch):
         worst_inj = max(worst_inj, e_inj)
         assert e_inj <= 1e-4, (n, e_inj)
     print(f"f32 arithmetic, worst per-entry gradient error / tensor scale: own decisions {worst_own:.2e}, oracle's {worst_inj:.2e}")
+
+
+def test_optimizer_state_dict_resume_equals_uninterrupted_run(fd):
+    """a run resumed from (model.state_dict(), optimizer.state_dict()) continues with its Adam moments
+    and bias-correction step: two steps in a row == one step, checkpoint round trip into fresh objects, one more step."""
+    from fdet_amd.models import ModelMeta
+    F_, size, S, B = 16, 480, 10, 2
+    spec = O.poolresnet_spec(F_, (3, size, size), S)
+    P = O.init_params(spec, seed=7)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.rand(B, 3, size, size, generator=g).cuda() for _ in range(2)]
+    ys = [torch.stack([O.encode_targets(b, (size, size), S) for b in O.synthetic_boxes(B, size, seed=s)]).cuda() for s in (1, 2)]
+    masks = [O.make_dropout_masks(spec, B, seed=s) for s in (11, 12)]
+
+    def fresh():
+        model = _load(_build(fd, "poolresnet", F_, size, S, 10), P).train()
+        mm = ModelMeta(model=model, lr=1e-4)
+        mm.configure_optimizers()
+        return model, mm
+
+    model_a, mm_a = fresh()
+    for i in range(2):
+        model_a.set_dropout_masks(masks[i]); mm_a.fused_train_step(xs[i], ys[i])
+    model_b, mm_b = fresh()
+    model_b.set_dropout_masks(masks[0]); mm_b.fused_train_step(xs[0], ys[0])
+    ck_model = {k: v.detach().cpu().clone() for k, v in model_b.state_dict().items()}
+    ck_opt = mm_b.opt.state_dict()
+    assert float(ck_opt["state"][0]["step"]) == 1.0 and len(ck_opt["state"]) == len(list(model_b.parameters()))
+    model_c, mm_c = fresh()
+    model_c.load_state_dict(ck_model)
+    mm_c.opt.load_state_dict(ck_opt)
+    assert mm_c.opt.step_count == 1
+    model_c.set_dropout_masks(masks[1]); mm_c.fused_train_step(xs[1], ys[1])
+    for (n, pa), (_, pc) in zip(model_a.named_parameters(), model_c.named_parameters()):
+        assert torch.equal(pa.detach().cpu(), pc.detach().cpu()), n          # same kernels, same inputs: bit for bit
+    # a resume WITHOUT the optimizer state restarts the bias correction: visibly different parameters
+    model_d, mm_d = fresh()
+    model_d.load_state_dict(ck_model)
+    model_d.set_dropout_masks(masks[1]); mm_d.fused_train_step(xs[1], ys[1])
+    assert any(not torch.equal(pa.detach().cpu(), pd.detach().cpu())
+               for (_, pa), (_, pd) in zip(model_a.named_parameters(), model_d.named_parameters()))
