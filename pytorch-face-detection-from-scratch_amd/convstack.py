@@ -130,6 +130,11 @@ class ConvStack:
         # pooled blocks: dropout*skip*maxpool (and its backward) inside the conv epilogues (FDET_POOL_FUSION=0: the
         # separate elementwise tail kernels of round 1)
         self.pool_fusion = self.x3 and os.environ.get("FDET_POOL_FUSION", "1") != "0"
+        # weight gradients on a second HIP stream: they depend only on tensors the data-gradient chain has already
+        # produced, so the batched weight-gradient launch of one resolution runs beside the data-gradient kernels of the
+        # next (and the last one beside the stem's); joined before anything reads the gradients (FDET_WGRAD_STREAM=0: off)
+        self.wgrad_stream = os.environ.get("FDET_WGRAD_STREAM", "1") != "0"
+        self._side = None
 
     def _t(self, kind: str, N: int, h: int, flops: float = 0.0, nbytes: float = 0.0):
         if self.timer is None:
@@ -294,16 +299,35 @@ class ConvStack:
                         G["out.weight"], G["out.bias"], ws, g.head_k, g.head_p)
         pending = []          # (x, dz, weight name) of same-resolution convs awaiting one batched wgrad launch
 
+        side_keep = []        # tensors in use on the side stream: referenced until the streams are joined
+        main = torch.cuda.current_stream(dev)
+        side = None
+        if self.wgrad_stream:
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+
+        def join():
+            """Everything queued on the side stream happens before whatever the main stream is given next."""
+            if side is not None and side_keep:
+                main.wait_stream(side)
+                side_keep.clear()
+
         def flush(hk_):
             if not pending:
                 return
             fl_ = self._conv_flops(N, hk_)
-            for i0 in range(0, len(pending), 16):
-                grp = pending[i0:i0 + 16]
-                wsb_ = self._workspace("wgrad_batched", hp.conv3x3_wgrad_batched_ws_bytes(len(grp), N, F_, F_, hk_, hk_), dev)
-                with self._t("conv3x3_wgrad", N, hk_, fl_ * len(grp), self._act_bytes(N, hk_, 2) * len(grp)):
-                    hp.conv3x3_wgrad_batched([p_[0] for p_ in grp], [p_[1] for p_ in grp],
-                                             [G[p_[2] + ".weight"] for p_ in grp], [G[p_[2] + ".bias"] for p_ in grp], wsb_)
+            if side is not None:
+                side.wait_stream(main)                    # the operands were produced on the main stream
+            with (torch.cuda.stream(side) if side is not None else _NOSPAN):
+                for i0 in range(0, len(pending), 16):
+                    grp = pending[i0:i0 + 16]
+                    wsb_ = self._workspace("wgrad_batched", hp.conv3x3_wgrad_batched_ws_bytes(len(grp), N, F_, F_, hk_, hk_), dev)
+                    with self._t("conv3x3_wgrad", N, hk_, fl_ * len(grp), self._act_bytes(N, hk_, 2) * len(grp)):
+                        hp.conv3x3_wgrad_batched([p_[0] for p_ in grp], [p_[1] for p_ in grp],
+                                                 [G[p_[2] + ".weight"] for p_ in grp], [G[p_[2] + ".bias"] for p_ in grp], wsb_)
+            if side is not None:
+                side_keep.extend(pending)
             pending.clear()
 
         # runs of blocks that went through the forward chain come back through the backward chain
@@ -341,6 +365,7 @@ class ConvStack:
                 if k == 0 or self.lv[k - 1][0] != hk:
                     flush(hk)
                     if after_block is not None:
+                        join()                            # the gradient bucket is about to be reduced
                         for q in range(k, g.num_blocks):
                             if self.lv[q][0] == hk:
                                 after_block(q)
@@ -386,6 +411,7 @@ class ConvStack:
                 if k == 0 or self.lv[k - 1][0] != hk:
                     flush(hk)
                     if after_block is not None:
+                        join()
                         for kk in range(k, g.num_blocks):
                             if self.lv[kk][0] == hk:
                                 after_block(kk)
@@ -396,6 +422,7 @@ class ConvStack:
         with self._t("stem_wgrad", N, self.h0, stem_flops, 4.0 * N * (g.in_ch * g.H * g.W + F_ * self.h0 * self.h0)):
             hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p,
                           x3=self.x3 and g.W % 16 == 0 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p))
+        join()
 
 
 def param_names(num_blocks: int) -> List[str]:
