@@ -92,6 +92,12 @@ class BaseModel(nn.Module):
         thresholds and weights are those at capture time (re-capture after changing them)."""
         return GraphedPredict(self, example)
 
+    def to_torchscript(self, file_path=None):
+        """`torch.jit.script(model)` of the reference's export scripts (convert_checkpoint_to_scripted_model.py:51-54): the
+        scriptable twin of this model (shared parameters, same state-dict names), optionally saved."""
+        from ..torchscript import to_torchscript
+        return to_torchscript(self, file_path)
+
     # -------------------------------------------------------------- reference surface
     def summary(self):
         if self.input_shape is None:

@@ -1,0 +1,174 @@
+"""TorchScript export through custom operators.
+
+The reference exports its trained models with `ModelMeta.to_torchscript(path)` (train_model.py:61) and
+`torch.jit.script(model)` (demo_scripts/convert_checkpoint_to_scripted_model.py:51-54); the shipped archives call
+`ops.torchvision.nms`.  The mirror's forward is a sequence of HIP launches behind a C-ABI, which TorchScript cannot see
+into, so the path is exposed to it as dispatcher operators (`torch.library`, namespace `fdet`):
+
+    fdet::preprocess(Tensor x, int height, int width) -> Tensor                      resize + /255 (PoolResnet.py:91-97)
+    fdet::stack_forward(Tensor x, Tensor[] params, int[] geometry) -> Tensor         the conv stack, eval mode
+    fdet::reduce_bounding_boxes(Tensor maps, float pt, float iou, float w, float h) -> (Tensor, Tensor)
+    fdet::nms(Tensor boxes, Tensor scores, float iou_threshold) -> Tensor            torchvision.ops.nms semantics
+
+and `ScriptableDetector` is a small scriptable module (same parameter names as the reference: `conv1`,
+`residual_blocks.k.conv{1,2}`, `out`) whose `forward(x, predict)` calls them.  A saved archive loads with
+`torch.jit.load` in any process that has imported this package (the operators are registered at import).  Inference
+only: the operators have no autograd formula (training goes through models.ModelMeta).
+
+`torchvision::nms` is registered too when torchvision is absent, so scripted code written against the reference
+(`torchvision.ops.nms(boxes, scores, iou_threshold)`) resolves to the HIP kernel.
+"""
+from __future__ import annotations
+
+import importlib.util
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import hotpath as hp
+from .convstack import ConvStack, StackGeometry, param_names
+
+_KINDS = ("poolresnet", "resnet")
+_engines: Dict[Tuple[int, ...], ConvStack] = {}
+_lib = None
+_tv_lib = None
+
+
+def _geometry_list(g: StackGeometry) -> List[int]:
+    return [_KINDS.index(g.kind), g.filters, g.in_ch, g.H, g.W, g.S, g.num_blocks, g.stem_k, g.stem_s, g.stem_p,
+            g.head_k, g.head_p, g.pool_mult]
+
+
+def _engine_for(geo: List[int]) -> ConvStack:
+    key = tuple(int(v) for v in geo)
+    if len(key) != 13:
+        raise ValueError(f"fdet::stack_forward: geometry must hold 13 integers, got {len(key)}")
+    eng = _engines.get(key)
+    if eng is None:
+        eng = ConvStack(StackGeometry(_KINDS[key[0]], *key[1:]))
+        _engines[key] = eng
+    return eng
+
+
+def _op_stack_forward(x: torch.Tensor, params: List[torch.Tensor], geo: List[int]) -> torch.Tensor:
+    eng = _engine_for(geo)
+    names = param_names(eng.geo.num_blocks)
+    if len(params) != len(names):
+        raise ValueError(f"fdet::stack_forward: expected {len(names)} parameter tensors, got {len(params)}")
+    P = {n: p.detach() for n, p in zip(names, params)}
+    return eng.forward(x.detach(), P, None, save=False)[0]
+
+
+def _op_preprocess(x: torch.Tensor, height: int, width: int) -> torch.Tensor:
+    if x.dim() == 3:
+        x = x.unsqueeze(0)
+    if tuple(x.shape[-2:]) != (height, width):
+        return hp.resize_bilinear_norm(x, (height, width))
+    if x.dtype == torch.uint8:
+        return hp.u8_to_f32_norm(x)
+    return x.float() / 255.0
+
+
+def _op_reduce(maps: torch.Tensor, pt: float, iou: float, w: float, h: float):
+    rows, counts = hp.reduce_bounding_boxes(maps, pt, iou, w, h)
+    return rows, counts.to(torch.int64)
+
+
+def _op_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    return hp.nms(boxes, scores, iou_threshold)
+
+
+def _no_cpu(name):
+    def fn(*args, **kwargs):
+        raise hp.N.FdetError(f"fdet::{name} runs on the GPU only (no CPU fallback): move the model and its inputs to cuda")
+    return fn
+
+
+def register_ops() -> None:
+    """Idempotent: defines the fdet:: operators (and torchvision::nms when torchvision is not installed)."""
+    global _lib, _tv_lib
+    if _lib is not None:
+        return
+    lib = torch.library.Library("fdet", "DEF")
+    lib.define("preprocess(Tensor x, int height, int width) -> Tensor")
+    lib.define("stack_forward(Tensor x, Tensor[] params, int[] geometry) -> Tensor")
+    lib.define("reduce_bounding_boxes(Tensor maps, float pt, float iou, float w, float h) -> (Tensor, Tensor)")
+    lib.define("nms(Tensor boxes, Tensor scores, float iou_threshold) -> Tensor")
+    for name, fn in (("preprocess", _op_preprocess), ("stack_forward", _op_stack_forward),
+                     ("reduce_bounding_boxes", _op_reduce), ("nms", _op_nms)):
+        lib.impl(name, fn, "CUDA")
+        lib.impl(name, _no_cpu(name), "CPU")
+    _lib = lib
+    if importlib.util.find_spec("torchvision") is None:
+        try:
+            tv = torch.library.Library("torchvision", "DEF")
+            tv.define("nms(Tensor dets, Tensor scores, float iou_threshold) -> Tensor")
+            tv.impl("nms", _op_nms, "CUDA")
+            tv.impl("nms", _no_cpu("nms"), "CPU")
+            _tv_lib = tv
+        except RuntimeError:                             # somebody else defined it first: leave theirs alone
+            _tv_lib = None
+
+
+register_ops()
+
+
+class _BlockParams(nn.Module):
+    """conv1 / conv2 parameter holder with the reference's names (models/PoolResnet.py:11-31)."""
+
+    def __init__(self, conv1: nn.Conv2d, conv2: nn.Conv2d):
+        super().__init__()
+        self.conv1 = conv1
+        self.conv2 = conv2
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:      # never called: the arithmetic is fdet::stack_forward
+        return x
+
+
+class ScriptableDetector(nn.Module):
+    """`forward(x, predict=tensor(0))` of the reference models (PoolResnet.py:93-105, Resnet.py:87-99) in eval mode,
+    written so that `torch.jit.script` accepts it.  Shares its parameters with the model it was built from."""
+
+    def __init__(self, model):
+        super().__init__()
+        g = model._geometry()
+        self.geometry: List[int] = _geometry_list(g)
+        self.height: int = int(g.H)
+        self.width: int = int(g.W)
+        self.num_of_patches: int = int(g.S)
+        self.probability_threshold: float = float(model.reduce_bounding_boxes.probability_threshold)
+        self.iou_threshold: float = float(model.reduce_bounding_boxes.iou_threshold)
+        self.conv1 = model.conv1
+        self.residual_blocks = nn.Sequential(*[_BlockParams(b.conv1, b.conv2) for b in model.residual_blocks])
+        self.out = model.out
+
+    def forward(self, x: torch.Tensor, predict: torch.Tensor = torch.tensor(0)) -> torch.Tensor:
+        want_boxes = bool(predict == 1)
+        if want_boxes:
+            x = torch.ops.fdet.preprocess(x, self.height, self.width)
+        params: List[torch.Tensor] = [self.conv1.weight, torch.jit._unwrap_optional(self.conv1.bias)]
+        for blk in self.residual_blocks:
+            params.append(blk.conv1.weight)
+            params.append(torch.jit._unwrap_optional(blk.conv1.bias))
+            params.append(blk.conv2.weight)
+            params.append(torch.jit._unwrap_optional(blk.conv2.bias))
+        params.append(self.out.weight)
+        params.append(torch.jit._unwrap_optional(self.out.bias))
+        y = torch.ops.fdet.stack_forward(x, params, self.geometry)
+        if want_boxes:
+            # boxes of image 0 only, as the reference (PoolResnet.py:103-104); (0,5) when nothing passes the threshold
+            rows, counts = torch.ops.fdet.reduce_bounding_boxes(y[0:1], self.probability_threshold, self.iou_threshold,
+                                                                float(self.width), float(self.height))
+            k = int(counts[0])
+            y = rows[0, :k]
+        return y
+
+
+def to_torchscript(model, file_path=None) -> torch.jit.ScriptModule:
+    """`torch.jit.script` of the model's inference path; saved to `file_path` when given (Lightning's
+    `LightningModule.to_torchscript(file_path)` contract, train_model.py:61)."""
+    scripted = torch.jit.script(ScriptableDetector(model).eval())
+    if file_path is not None:
+        torch.jit.save(scripted, str(file_path))
+    return scripted

@@ -526,3 +526,38 @@ def test_optimizer_state_dict_resume_equals_uninterrupted_run(fd):
     model_d.set_dropout_masks(masks[1]); mm_d.fused_train_step(xs[1], ys[1])
     assert any(not torch.equal(pa.detach().cpu(), pd.detach().cpu())
                for (_, pa), (_, pd) in zip(model_a.named_parameters(), model_d.named_parameters()))
+
+
+def test_torchscript_export_matches_eager(fd, golden, tmp_path):
+    """SURVEY.md 8f rank 4 (train_model.py:61, convert_checkpoint_to_scripted_model.py:51-54): the scripted module
+    (custom fdet:: operators) gives the eager model's maps and the eager demo-path boxes, before and after a
+    torch.jit.save / load round trip, with the shipped small PoolResnet weights."""
+    from fdet_amd.models.PoolResnet import PoolResnet
+    g = golden("g6_trained_small")
+    P = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    model = PoolResnet(filters=32, input_shape=(3, 480, 480), num_of_patches=10, probability_threshold=0.7,
+                       iou_threshold=0.01)
+    model = _load(model, P).eval()
+    path = tmp_path / "small_scripted.pt"
+    scripted = model.to_torchscript(str(path))
+    loaded = torch.jit.load(str(path))
+    for n in range(g["images"].shape[0]):
+        u8 = g["images"][n].cuda()
+        pair = torch.stack([u8, u8])
+        with torch.no_grad():
+            y_e = model(pair.float() / 255.0)
+            det_e = model(pair, predict=torch.tensor(1))
+            for sm in (scripted, loaded):
+                assert torch.equal(sm(pair.float() / 255.0), y_e)
+                det_s = sm(pair, torch.tensor(1))
+                assert det_s.shape == det_e.shape and torch.equal(det_s.cpu(), det_e.cpu())
+        nd = int(g["ndets"][n])                       # ... which are the reference's own detections (g6)
+        assert det_e.shape[0] == nd
+        if nd:
+            assert torch.equal(det_e[:, 1:].cpu(), g["dets"][n, :nd, 1:])
+    # torchvision.ops.nms as scripted reference code calls it resolves to the HIP kernel (torchvision is absent here)
+    boxes = torch.tensor([[0., 0., 10., 10.], [1., 1., 11., 11.], [20., 20., 30., 30.]]).cuda()
+    scores = torch.tensor([0.9, 0.8, 0.7]).cuda()
+    assert torch.ops.fdet.nms(boxes, scores, 0.5).tolist() == [0, 2]
+    if hasattr(torch.ops, "torchvision") and hasattr(torch.ops.torchvision, "nms"):
+        assert torch.ops.torchvision.nms(boxes, scores, 0.5).tolist() == [0, 2]

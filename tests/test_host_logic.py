@@ -178,3 +178,26 @@ def test_bench_self_launch_refuses_more_ranks_than_gpus_without_touching_one():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 2 and "GPU(s) are visible" in r.stderr and r.stdout.strip() == ""
+
+
+def test_torchscript_export_scripts_and_round_trips_without_a_gpu(tmp_path):
+    """SURVEY.md 8f rank 4: the inference path scripts (custom fdet:: operators), keeps the reference's state-dict names,
+    survives torch.jit.save / load, and -- like every op of this package -- refuses CPU tensors loudly."""
+    import fdet_amd
+    from fdet_amd.models import ModelMeta
+    m = PoolResnet(16, (3, 480, 480), 10)
+    mm = ModelMeta(model=m)
+    path = tmp_path / "scripted.pt"
+    sm = mm.to_torchscript(str(path))
+    kinds = [n.kind() for n in sm.graph.nodes()] + [n.kind() for b in sm.graph.nodes() for blk in b.blocks() for n in blk.nodes()]
+    assert "fdet::stack_forward" in kinds and "fdet::preprocess" in kinds and "fdet::reduce_bounding_boxes" in kinds
+    assert list(sm.state_dict().keys()) == param_names(10)
+    loaded = torch.jit.load(str(path))
+    assert list(loaded.state_dict().keys()) == param_names(10)
+    for k, v in m.state_dict().items():
+        assert torch.equal(loaded.state_dict()[k], v)
+    with pytest.raises(Exception, match="GPU only"):
+        loaded(torch.zeros(1, 3, 480, 480))
+    # Resnet (3x3 head, other pool rule) scripts too
+    r = Resnet(16, (3, 240, 240), 15, num_of_residual_blocks=6)
+    assert "fdet::stack_forward" in [n.kind() for n in r.to_torchscript().graph.nodes()]
