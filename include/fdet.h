@@ -280,6 +280,25 @@ int fdet_conv3x3_dgrad_unpool_bf16x3(const float* dz, const void* wpk, const flo
 int fdet_pool_route_bwd(const float* dout_pooled, const unsigned char* route, const float* drop_scale, float* dz2,
                         int N, int F, int H, int W, float slope, void* stream);
 
+/* Pointwise (1x1) convolution / per-position Linear layer as a dense GEMM on the matrix cores, bf16x3 arithmetic
+ * (fp32-level accuracy).  Replaces nn.Conv2d(Cin, Cout, 1) of SeparableResidualBlock.pointwise_conv_skip
+ * (models/SSD.py:24-30) and nn.Linear(C, 5) applied at every position (models/SSD.py:183-185) and their autograd.
+ * Tensors are [N, C, P] fp32 with P = H*W positions per image (NCHW); any Cin / Cout >= 1.
+ *   pack : w [Cout,Cin] -> K-major bf16 hi|lo panels; each buffer fdet_pointwise_packed_bytes(Cout, Cin) bytes
+ *   fwd  : y = lrelu_slope(W x + bias)         (slope 1 = identity; bias may be NULL)
+ *   dgrad: dx = W^T dz (+ add, may be NULL)
+ *   wgrad: dW [Cout,Cin] = sum_{n,p} dz x^T ; db [Cout] = sum dz (db may be NULL); deterministic slab reduction;
+ *          ws: fdet_pointwise_wgrad_ws_bytes(N, Cin, Cout, P) bytes of device scratch. */
+size_t fdet_pointwise_packed_bytes(int Cout, int Cin);
+int fdet_pack_pointwise_weights_bf16x3(const float* w, int Cout, int Cin, void* wpk_fwd, void* wpk_bwd, void* stream);
+int fdet_pointwise_fwd_bf16x3(const float* x, const void* wpk_fwd, const float* bias, float* y, int N, int Cin, int Cout,
+                              int P, float slope, void* stream);
+int fdet_pointwise_dgrad_bf16x3(const float* dz, const void* wpk_bwd, const float* add, float* dx, int N, int Cin,
+                                int Cout, int P, void* stream);
+size_t fdet_pointwise_wgrad_ws_bytes(int N, int Cin, int Cout, int P);
+int fdet_pointwise_wgrad_bf16x3(const float* x, const float* dz, float* dW, float* db, void* ws, size_t ws_bytes, int N,
+                                int Cin, int Cout, int P, void* stream);
+
 /* Backward of the residual-block tail (dropout, skip, max-pool, second LeakyReLU):
  *   e = c*drop_scale + x ; out = maxpool(e) ; given dout [N,F,H/pool,W/pool]:
  *   de = unpool(dout) (first max in window scan order wins, as ATen max_pool2d backward)

@@ -70,6 +70,12 @@ SIGNATURES = {
     "fdet_conv3x3_fwd_pool_bf16x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_dgrad_unpool_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_pool_route_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "fdet_pointwise_packed_bytes": (_SZ, [_I, _I]),
+    "fdet_pack_pointwise_weights_bf16x3": (_I, [_P, _I, _I, _P, _P, _P]),
+    "fdet_pointwise_fwd_bf16x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "fdet_pointwise_dgrad_bf16x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fdet_pointwise_wgrad_ws_bytes": (_SZ, [_I, _I, _I, _I]),
+    "fdet_pointwise_wgrad_bf16x3": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "fdet_conv3x3_wgrad_ws_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "fdet_conv3x3_wgrad": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P]),
     "fdet_conv3x3_wgrad_bf16x3_ws_bytes": (_SZ, [_I, _I, _I, _I, _I]),

@@ -417,6 +417,59 @@ def pool_route_bwd(dout_pooled, route, drop_scale, dz2, slope: float = 0.2):
                                     float(slope), stream()), "fdet_pool_route_bwd")
 
 
+# ---- pointwise (1x1 conv / per-position Linear) GEMMs, bf16x3 ------------------------------------------------------
+def pointwise_pack(w: torch.Tensor):
+    """w (Cout,Cin[,1,1]) -> (forward panel, backward panel) for pointwise_fwd / pointwise_dgrad."""
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    w2 = _f32(w.reshape(cout, cin))
+    n = int(lib().fdet_pointwise_packed_bytes(cout, cin)) // 4
+    f_ = torch.empty(n, dtype=F32, device=w.device)
+    b_ = torch.empty(n, dtype=F32, device=w.device)
+    check(lib().fdet_pack_pointwise_weights_bf16x3(ptr(w2), cout, cin, ptr(f_), ptr(b_), stream()), "fdet_pack_pointwise_weights_bf16x3")
+    return f_, b_
+
+
+def pointwise_fwd(x, wpk_fwd, bias, y, slope: float = 1.0):
+    """y (N,Cout,H,W) = lrelu_slope(W x + bias) for x (N,Cin,H,W)."""
+    Nn, cin = x.shape[0], x.shape[1]
+    cout = y.shape[1]
+    P = x.numel() // (Nn * cin)
+    if y.shape[0] != Nn or y.numel() != Nn * cout * P:
+        raise ValueError("pointwise_fwd: x / y shapes disagree")
+    if bias is not None:
+        _chk4(bias, (cout,), "bias")
+    if wpk_fwd.numel() * 4 < int(lib().fdet_pointwise_packed_bytes(cout, cin)):
+        raise ValueError("pointwise_fwd: packed weight buffer too small for (Cout,Cin)")
+    check(lib().fdet_pointwise_fwd_bf16x3(ptr(x), ptr(wpk_fwd), ptr(bias), ptr(y), Nn, cin, cout, P, float(slope), stream()),
+          "fdet_pointwise_fwd_bf16x3")
+
+
+def pointwise_dgrad(dz, wpk_bwd, dx, add=None):
+    """dx (N,Cin,H,W) = W^T dz (+ add)."""
+    Nn, cout = dz.shape[0], dz.shape[1]
+    cin = dx.shape[1]
+    P = dz.numel() // (Nn * cout)
+    if dx.shape[0] != Nn or dx.numel() != Nn * cin * P or (add is not None and tuple(add.shape) != tuple(dx.shape)):
+        raise ValueError("pointwise_dgrad: shapes disagree")
+    if wpk_bwd.numel() * 4 < int(lib().fdet_pointwise_packed_bytes(cout, cin)):
+        raise ValueError("pointwise_dgrad: packed weight buffer too small for (Cout,Cin)")
+    check(lib().fdet_pointwise_dgrad_bf16x3(ptr(dz), ptr(wpk_bwd), ptr(add), ptr(dx), Nn, cin, cout, P, stream()),
+          "fdet_pointwise_dgrad_bf16x3")
+
+
+def pointwise_wgrad(x, dz, dW, db=None):
+    """dW (Cout,Cin[,1,1]) = sum dz x^T, db (Cout,) = sum dz."""
+    Nn, cin = x.shape[0], x.shape[1]
+    cout = dz.shape[1]
+    P = x.numel() // (Nn * cin)
+    if dz.shape[0] != Nn or dz.numel() != Nn * cout * P or dW.numel() != cout * cin or (db is not None and db.numel() != cout):
+        raise ValueError("pointwise_wgrad: shapes disagree")
+    nb = int(lib().fdet_pointwise_wgrad_ws_bytes(Nn, cin, cout, P))
+    ws = torch.empty(nb // 4 + 4, dtype=F32, device=x.device)
+    check(lib().fdet_pointwise_wgrad_bf16x3(ptr(x), ptr(dz), ptr(dW), ptr(db), ptr(ws), ws.numel() * 4, Nn, cin, cout, P, stream()),
+          "fdet_pointwise_wgrad_bf16x3")
+
+
 def conv3x3_wgrad_ws_bytes(Nn, cin, cout, H, W) -> int:
     """Workspace that serves BOTH precisions of conv3x3_wgrad."""
     return max(int(lib().fdet_conv3x3_wgrad_ws_bytes(Nn, cin, cout, H, W)),

@@ -64,14 +64,6 @@ class SSDStack:
         self.slope = 0.2
 
     # ------------------------------------------------------------------ weights
-    @staticmethod
-    def _centre_tap(w: torch.Tensor, cout_pad: int) -> torch.Tensor:
-        """(co,ci[,1,1]) pointwise weights as a 3x3 kernel whose only non-zero tap is the centre."""
-        w2 = w.reshape(w.shape[0], w.shape[1])
-        w3 = torch.zeros(cout_pad, w2.shape[1], 3, 3, dtype=F32, device=w.device)
-        w3[: w2.shape[0], :, 1, 1] = w2
-        return w3
-
     def _pack(self, key: str, w3: torch.Tensor):
         co, ci = w3.shape[0], w3.shape[1]
         nf, nb = hp.packed_sizes(co, ci)
@@ -80,21 +72,22 @@ class SSDStack:
             self._wpk[key + ".b"] = torch.empty(nb, dtype=F32, device=w3.device)
         hp.pack_conv3x3_weights(w3.contiguous(), self._wpk[key + ".f"], self._wpk[key + ".b"], x3=True)
 
+    def _pack_pointwise(self, key: str, w: torch.Tensor):
+        """1x1 skip convs and the Linear heads are dense GEMMs: K-major bf16 hi|lo panels of fdet_pointwise_*_bf16x3."""
+        self._wpk[key + ".f"], self._wpk[key + ".b"] = hp.pointwise_pack(w)
+
     def _ensure_packed(self, P):
         key = tuple((P[k].data_ptr(), P[k]._version) for k in sorted(P) if k.endswith("weight"))
         if key == self._key:
             return
         for name, ci, co, _, head in self.specs:
             if ci != co:
-                self._pack(name + ".skip", self._centre_tap(P[name + ".pointwise_conv_skip.weight"], co))
+                self._pack_pointwise(name + ".skip", P[name + ".pointwise_conv_skip.weight"])
             self._pack(name + ".conv1", P[name + ".conv1.weight"])
             self._pack(name + ".conv2", P[name + ".conv2.weight"])
             if head >= 0:
                 hn = f"extracting_layers.{head}.0"
-                self._pack(hn, self._centre_tap(P[hn + ".weight"], HEAD_CP))
-                b = torch.zeros(HEAD_CP, dtype=F32, device=P[hn + ".bias"].device)
-                b[:5] = P[hn + ".bias"]
-                self._wpk[hn + ".bias16"] = b
+                self._pack_pointwise(hn, P[hn + ".weight"])
         self._key = key
 
     def mark_params_dirty(self):
@@ -128,8 +121,7 @@ class SSDStack:
                 skip = h
             else:
                 skip = torch.empty(N, co, hk, hk, dtype=F32, device=dev)
-                hp.conv3x3_fwd(h, self._wpk[name + ".skip.f"], P[name + ".pointwise_conv_skip.bias"], co, y_full=skip,
-                               slope=1.0, x3=True)
+                hp.pointwise_fwd(h, self._wpk[name + ".skip.f"], P[name + ".pointwise_conv_skip.bias"], skip)
             a = torch.empty(N, co, hk, hk, dtype=F32, device=dev)
             hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], co, y_full=a, slope=self.slope, x3=True)
             ho = hk // 2 if pool else hk
@@ -146,8 +138,8 @@ class SSDStack:
             h = out
             if head >= 0:
                 hn = f"extracting_layers.{head}.0"
-                z = torch.empty(N, HEAD_CP, ho, ho, dtype=F32, device=dev)
-                hp.conv3x3_fwd(h, self._wpk[hn + ".f"], self._wpk[hn + ".bias16"], HEAD_CP, y_full=z, slope=1.0, x3=True)
+                z = torch.empty(N, 5, ho, ho, dtype=F32, device=dev)       # Linear(C,5) at every position
+                hp.pointwise_fwd(h, self._wpk[hn + ".f"], P[hn + ".bias"], z)
                 hp.ssd_head_pack_fwd(z, PATCH_SIZES[head], self.starts[head], y)
                 if save:
                     saved["heads"][head] = h
@@ -180,13 +172,11 @@ class SSDStack:
             if head >= 0:                                   # the head reads this block's output
                 hn = f"extracting_layers.{head}.0"
                 hout = saved["heads"][head]
-                dz = torch.empty(N, HEAD_CP, ho, ho, dtype=F32, device=dev)
+                dz = torch.empty(N, 5, ho, ho, dtype=F32, device=dev)
                 hp.ssd_head_pack_bwd(dy, y, PATCH_SIZES[head], self.starts[head], dz)
-                dW3, db16 = self._wgrad(hout, dz, dev)
-                G[hn + ".weight"].copy_(dW3[:5, :, 1, 1])
-                G[hn + ".bias"].copy_(db16[:5])
+                hp.pointwise_wgrad(hout, dz, G[hn + ".weight"], G[hn + ".bias"])
                 dout = torch.empty_like(hout)
-                hp.conv3x3_dgrad(dz, self._wpk[hn + ".b"], co, dout, add=dtrunk, slope=1.0, x3=True)
+                hp.pointwise_dgrad(dz, self._wpk[hn + ".b"], dout, add=dtrunk)
             else:
                 dout = dtrunk
             sc = masks[name] if masks is not None else None
@@ -206,10 +196,9 @@ class SSDStack:
             if ci == co:
                 addt = de
             else:
-                dW3, dbs = self._wgrad(hin, de, dev)
-                G[name + ".pointwise_conv_skip.weight"].copy_(dW3[:, :, 1:2, 1:2]); G[name + ".pointwise_conv_skip.bias"].copy_(dbs)
+                hp.pointwise_wgrad(hin, de, G[name + ".pointwise_conv_skip.weight"], G[name + ".pointwise_conv_skip.bias"])
                 addt = torch.empty_like(hin)
-                hp.conv3x3_dgrad(de, self._wpk[name + ".skip.b"], ci, addt, slope=1.0, x3=True)
+                hp.pointwise_dgrad(de, self._wpk[name + ".skip.b"], addt)
             dx = torch.empty_like(hin)
             hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], ci, dx, add=addt, slope=self.slope, x3=True)
             dtrunk = dx

@@ -319,3 +319,41 @@ def test_pooled_block_fused_into_conv_epilogues(hp, shape):
     F.max_pool2d(er, 2).backward(dout)
     full_decided = decided.reshape(N, C, H // 2, W // 2, 1, 1).expand(-1, -1, -1, -1, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H, W)
     assert torch.equal(de_full[full_decided], er.grad[full_decided])
+
+
+PW_SHAPES = [(2, 16, 32, 24, 24), (3, 32, 64, 60, 60), (2, 64, 128, 15, 15), (2, 128, 256, 30, 30), (2, 256, 5, 15, 15),
+             (3, 256, 5, 7, 7), (1, 128, 5, 60, 60), (2, 24, 40, 9, 13), (1, 3, 7, 5, 6)]
+
+
+@pytest.mark.parametrize("shape", PW_SHAPES)
+def test_pointwise_gemm_fwd_dgrad_wgrad(hp, shape):
+    """1x1 conv / per-position Linear as dense GEMMs (fdet_pointwise_*_bf16x3) against torch fp32 CPU: forward with bias
+    and optional LeakyReLU, data gradient with the fused add, weight and bias gradient.  1e-4 of the tensor scale.
+    Shapes: the SSD skip convs and heads (models/SSD.py:24-30,183-185), odd channel counts, planes that are not multiples
+    of 4 / 16 positions (unaligned rows: the dword path)."""
+    N, Ci, Co, H, W = shape
+    g = torch.Generator().manual_seed(N + Ci + Co + H)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 1, 1, generator=g) * 0.2
+    b = torch.randn(Co, generator=g)
+    wf, wb = hp.pointwise_pack(w.cuda())
+    y = torch.full((N, Co, H, W), float("nan"), device="cuda")
+    hp.pointwise_fwd(x.cuda(), wf, b.cuda(), y)
+    ref = F.conv2d(x, w, b)
+    close(y, ref)
+    y2 = torch.full((N, Co, H, W), float("nan"), device="cuda")
+    hp.pointwise_fwd(x.cuda(), wf, None, y2, slope=0.2)
+    close(y2, F.leaky_relu(F.conv2d(x, w), 0.2))
+    dz = torch.randn(N, Co, H, W, generator=g)
+    add = torch.randn(N, Ci, H, W, generator=g)
+    dx = torch.full((N, Ci, H, W), float("nan"), device="cuda")
+    hp.pointwise_dgrad(dz.cuda(), wb, dx, add=add.cuda())
+    close(dx, F.conv_transpose2d(dz, w) + add)
+    hp.pointwise_dgrad(dz.cuda(), wb, dx)
+    close(dx, F.conv_transpose2d(dz, w))
+    dW = torch.full((Co, Ci, 1, 1), float("nan"), device="cuda"); db = torch.full((Co,), float("nan"), device="cuda")
+    hp.pointwise_wgrad(x.cuda(), dz.cuda(), dW, db)
+    wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    F.conv2d(x, wr, br).backward(dz)
+    close(dW, wr.grad)
+    close(db, br.grad)
