@@ -144,3 +144,50 @@ def test_ssd_fused_train_step_vs_oracle():
         d = (p.detach().cpu() - Pn[n]).abs()
         assert float(d.max()) <= 2.1e-4, n
         assert int((d > 2e-6).sum()) <= max(3, int(0.03 * d.numel())), n
+
+
+@pytest.mark.timeout(900)
+def test_ssd_config4_batch512_is_concatenation_of_its_halves():
+    """BASELINE.json config 4 at ITS batch size (SSD filters 16, 3x480x480, 4774 priors, 512 images): size-independent
+    properties.  The forward of the batch is bit for bit the concatenation of its halves; `ssd_loss` divides by the
+    positive-prior count of the WHOLE batch (losses/SSDLoss.py:86), so loss and parameter gradients of the halves
+    combine weighted by their positive counts:  L * n = L_a * n_a + L_b * n_b  (and the same for every gradient)."""
+    import fdet_amd
+    from fdet_amd import hotpath as hp
+    from fdet_amd.models.SSD import SSD
+    from oracle import ssd_model_oracle as SM
+    fil, B = 16, 512
+    P = SM.init_params(fil, seed=21)
+    model = SSD(filters=fil, input_shape=(3, SIZE, SIZE))
+    model.load_state_dict({k: v.clone() for k, v in P.items()})
+    model = model.cuda().train()
+    eng = model.engine
+    names, params = model.named_stack_params()
+    Pd = {n: p.data for n, p in zip(names, params)}
+    x = torch.rand(B, 3, SIZE, SIZE, generator=torch.Generator().manual_seed(22)).cuda()
+    boxes = O.synthetic_boxes(B, SIZE, seed=23, max_faces=6)
+    tgt = hp.ssd_encode_targets(boxes, (SIZE, SIZE))
+    masks = {k: v.cuda() for k, v in SM.make_dropout_masks(fil, B, seed=24).items()}
+    npos = (tgt[:, :, 0] > 0).sum(dim=1).double().cpu()
+
+    def run(sl):
+        m_ = {k: v[sl].contiguous() for k, v in masks.items()}
+        y, saved = eng.forward(x[sl].contiguous(), Pd, m_, save=True)
+        loss, dy, _ = hp.ssd_loss_fwd_bwd(y, tgt[sl].contiguous(), 10, want_grad=True)
+        G = {n: torch.empty_like(p) for n, p in Pd.items()}
+        eng.backward(saved, dy, Pd, G)
+        del saved
+        return y, float(loss), {n: v.double().cpu() for n, v in G.items()}
+
+    y_all, l_all, G_all = run(slice(0, B))
+    y_a, l_a, G_a = run(slice(0, B // 2))
+    y_b, l_b, G_b = run(slice(B // 2, B))
+    assert tuple(y_all.shape) == (B, 4774, 5) and bool(torch.isfinite(y_all).all())
+    assert torch.equal(y_all, torch.cat([y_a, y_b]))
+    n_a, n_b = float(npos[: B // 2].sum()), float(npos[B // 2:].sum())
+    n_all = n_a + n_b
+    assert abs(l_all * n_all - (l_a * n_a + l_b * n_b)) <= 1e-4 * abs(l_all * n_all)
+    for n in names:
+        tot = (G_a[n] * n_a + G_b[n] * n_b) / n_all
+        scale = max(1e-9, float(tot.abs().max()))
+        assert float((G_all[n] - tot).abs().max()) <= 2e-4 * scale, n
