@@ -651,3 +651,83 @@ def head_bwd(x, drop_scale, w, y, dy, dx, dW, db, ws, k, pad):
     check(lib().fdet_head_bwd(ptr(x), ptr(drop_scale), ptr(w), ptr(y), ptr(dy), ptr(dx), ptr(dW), ptr(db),
                               ptr(ws, ws.dtype), ws.numel() * ws.element_size(), Nn, F_, H, W, k, pad, stream()),
           "fdet_head_bwd")
+
+
+# ---- MobileNetV3 backbone (inference, bf16, NHWC activations) -------------------------------------------------------
+BF16 = torch.bfloat16
+MB_ACT = {"none": 0, "relu": 1, "hswish": 2}
+
+
+def mb_stem(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """x (N,3,H,W) f32 in [0,1] or uint8 (the /255 fused) -> (N,H/2,W/2,16) bf16; w (16,27) f32 BN-folded."""
+    if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 2 or x.shape[3] % 2 or x.dtype not in (F32, torch.uint8):
+        raise ValueError(f"mb_stem: expected (N,3,H,W) f32/uint8 with even H, W; got {tuple(x.shape)} {x.dtype}")
+    _chk4(w, (16, 27), "stem weight"); _chk4(bias, (16,), "stem bias")
+    Nn, _, H, W = x.shape
+    y = torch.empty(Nn, H // 2, W // 2, 16, dtype=BF16, device=x.device)
+    check(lib().fdet_mb_stem(ptr(x, x.dtype), int(x.dtype == torch.uint8), ptr(w), ptr(bias), ptr(y, BF16), Nn, H, W, stream()),
+          "fdet_mb_stem")
+    return y
+
+
+def mb_depthwise(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, K: int, stride: int, act: int, want_pool: bool):
+    """x (N,H,W,C) bf16 -> (y (N,Ho,Wo,C) bf16, per-image channel sums (N,C) f32 or None); w (K*K,C) f32."""
+    if x.dim() != 4 or x.dtype != BF16:
+        raise ValueError("mb_depthwise: expected (N,H,W,C) bf16")
+    Nn, H, W, C = x.shape
+    _chk4(w, (K * K, C), "depthwise weight"); _chk4(bias, (C,), "depthwise bias")
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    y = torch.empty(Nn, Ho, Wo, C, dtype=BF16, device=x.device)
+    pool = torch.empty(Nn, C, dtype=F32, device=x.device) if want_pool else None
+    check(lib().fdet_mb_depthwise(ptr(x, BF16), ptr(w), ptr(bias), ptr(y, BF16), ptr(pool), Nn, H, W, C, K, stride, act, stream()),
+          "fdet_mb_depthwise")
+    return y, pool
+
+
+def mb_se_gate(pool: torch.Tensor, HW: int, w1, b1, w2, b2) -> torch.Tensor:
+    Nn, C = pool.shape
+    R = w1.shape[0]
+    _chk4(w1, (R, C), "se reduce weight"); _chk4(b1, (R,), "se reduce bias")
+    _chk4(w2, (C, R), "se expand weight"); _chk4(b2, (C,), "se expand bias")
+    gate = torch.empty(Nn, C, dtype=F32, device=pool.device)
+    check(lib().fdet_mb_se_gate(ptr(pool), HW, ptr(w1), ptr(b1), ptr(w2), ptr(b2), Nn, C, R, ptr(gate), stream()), "fdet_mb_se_gate")
+    return gate
+
+
+def mb_pointwise_pack(w: torch.Tensor, bias: torch.Tensor):
+    """BN-folded (Cout,Cin) f32 weight + (Cout,) bias -> (bf16 panel [ceil32(Cout)][ceil16(Cin)], f32 bias [ceil32(Cout)])."""
+    cout, cin = w.shape
+    cop, cip = -(-cout // 32) * 32, -(-cin // 16) * 16
+    wp = torch.zeros(cop, cip, dtype=BF16, device=w.device)
+    wp[:cout, :cin] = w.to(BF16)
+    bp = torch.zeros(cop, dtype=F32, device=w.device)
+    bp[:cout] = bias
+    return wp, bp
+
+
+def mb_pointwise(x: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, cout: int, act: int, gate=None, res=None) -> torch.Tensor:
+    """y (N,H,W,Cout) bf16 = act(W (x * gate) + bias) (+ res) for x (N,H,W,Cin) bf16."""
+    if x.dim() != 4 or x.dtype != BF16:
+        raise ValueError("mb_pointwise: expected (N,H,W,C) bf16")
+    Nn, H, W, cin = x.shape
+    if tuple(wp.shape) != (-(-cout // 32) * 32, -(-cin // 16) * 16) or wp.dtype != BF16 or bp.numel() != wp.shape[0]:
+        raise ValueError(f"mb_pointwise: weight panel {tuple(wp.shape)} does not fit Cout={cout}, Cin={cin}")
+    if gate is not None:
+        _chk4(gate, (Nn, cin), "gate")
+    y = torch.empty(Nn, H, W, cout, dtype=BF16, device=x.device)
+    if res is not None and (tuple(res.shape) != tuple(y.shape) or res.dtype != BF16):
+        raise ValueError("mb_pointwise: residual must match the output")
+    check(lib().fdet_mb_pointwise(ptr(x, BF16), ptr(wp, BF16), ptr(bp), ptr(gate), ptr(res, BF16), ptr(y, BF16), Nn, H * W, cin,
+                                  cout, act, stream()), "fdet_mb_pointwise")
+    return y
+
+
+def mb_head(f: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """f (N,S,S,C) bf16 -> sigmoid(Conv2d(C,5,3,p1)) as (N,5,S,S) f32; w (5,9,C) f32."""
+    if f.dim() != 4 or f.dtype != BF16 or f.shape[1] != f.shape[2]:
+        raise ValueError("mb_head: expected (N,S,S,C) bf16")
+    Nn, S, _, C = f.shape
+    _chk4(w, (5, 9, C), "head weight"); _chk4(bias, (5,), "head bias")
+    y = torch.empty(Nn, 5, S, S, dtype=F32, device=f.device)
+    check(lib().fdet_mb_head(ptr(f, BF16), ptr(w), ptr(bias), ptr(y), Nn, S, C, stream()), "fdet_mb_head")
+    return y

@@ -201,3 +201,28 @@ def test_torchscript_export_scripts_and_round_trips_without_a_gpu(tmp_path):
     # Resnet (3x3 head, other pool rule) scripts too
     r = Resnet(16, (3, 240, 240), 15, num_of_residual_blocks=6)
     assert "fdet::stack_forward" in [n.kind() for n in r.to_torchscript().graph.nodes()]
+
+
+def test_mobilenet_mirror_state_dict_names_and_loud_failures():
+    """models/MobilenetV3Backbone.py:11-60 mirror: same ctor signature, the state-dict names/shapes of the reference's
+    module tree (so its checkpoints load by name), and no CPU fallback."""
+    import inspect
+    import warnings
+    from fdet_amd import _native as N
+    from fdet_amd.models.MobilenetV3Backbone import MobilenetV3Backbone
+    from oracle import mobilenet_oracle as MO
+    sig = list(inspect.signature(MobilenetV3Backbone.__init__).parameters)
+    assert sig == ["self", "filters", "input_shape", "num_of_patches", "probability_threshold", "iou_threshold", "pretrained",
+                   "input_kernel_size", "input_stride", "output_kernel_size", "output_padding"]
+    with pytest.warns(UserWarning):
+        MobilenetV3Backbone(64, (3, 480, 480), 15)               # pretrained=True: no download is attempted, says so
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        net = MobilenetV3Backbone(64, (3, 480, 480), 15, pretrained=False).eval()
+    sd = net.state_dict()
+    assert list(sd.keys()) == MO.param_names()
+    assert all(tuple(sd[n].shape) == tuple(s) for n, s in MO.param_shapes().items())
+    with pytest.raises(N.FdetError):
+        net(torch.rand(1, 3, 480, 480))                          # CPU tensors: loud, no fallback
+    with pytest.raises(ValueError):
+        MobilenetV3Backbone(64, (3, 480, 480), 10, pretrained=False)      # stride 32 gives a 15x15 grid

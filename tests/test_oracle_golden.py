@@ -248,3 +248,25 @@ def test_reference_poolresnet_f16_train_step(golden):
     for k in G:
         ref = g["grad/" + k]
         assert torch.allclose(G[k], ref, atol=1e-5 + 1e-4 * float(ref.abs().max()), rtol=1e-4), k
+
+
+def test_mobilenet_fixture_and_oracle_shapes(golden):
+    """g13 = the parameter tensors of the reference's shipped MobileNetV3 archive (raw storage bytes,
+    tools/make_goldens_mobilenet.py).  PARITY UNPINNED for this model: no reference output exists (timm absent, archive not
+    executable) -- this pins only that the fixture holds exactly the architecture's 242 tensors, that the values look like a
+    trained network, and that the oracle runs on them."""
+    from oracle import mobilenet_oracle as MO
+    P = golden("g13_mobilenet_weights")
+    names, shapes = MO.param_names(), MO.param_shapes()
+    assert list(P.keys()) == names and len(names) == 242
+    for n in names:
+        assert tuple(P[n].shape) == tuple(shapes[n]), n
+        assert bool(torch.isfinite(P[n].float()).all()), n
+    assert int(P["feature_extractor.1.num_batches_tracked"]) > 0
+    for n in names:
+        if n.endswith("running_var"):
+            assert float(P[n].min()) > 0.0, n
+    x = torch.rand(1, 3, 96, 96, generator=torch.Generator().manual_seed(0))
+    y = MO.model_forward(P, x)
+    assert tuple(y.shape) == (1, 5, 3, 3) and bool(((y > 0) & (y < 1)).all())
+    assert tuple(MO.features(MO.init_params(1), x).shape) == (1, 576, 3, 3)
