@@ -310,7 +310,9 @@ int fdet_pointwise_wgrad_bf16x3(const float* x, const float* dz, float* dW, floa
  *   fdet_mb_se_gate   gate [N][C] = hardsigmoid(W2 relu(W1 (pool / HW) + b1) + b2); w1 [R][C], w2 [C][R] f32
  *   fdet_mb_pointwise y [N,P,Cout] = act(W (x * gate) + bias) (+ res); x [N,P,Cin]; w bf16 [ceil32(Cout)][ceil16(Cin)] zero
  *                     padded; bias f32 [ceil32(Cout)]; gate [N][Cin] or NULL; res [N,P,Cout] or NULL
- *   fdet_mb_head      y [N,5,S,S] f32 = sigmoid(Conv2d(C,5,3,p1)(f)); f [N,S,S,C] bf16; w [5][9][C] f32, bias [5] */
+ *   fdet_mb_head      y [N,5,S,S] f32 = sigmoid(Conv2d(C,5,3,p1)(f)); f [N,S,S,C] bf16 (C % 16 == 0); w bf16 [2][64][C]: row
+ *                     tap*5 + ch of the fp32 weight (rows 45..63 zero) split into hi = bf16(w) and lo = bf16(w - hi); bias [5]
+ *                     f32; ws >= fdet_mb_head_ws_bytes(N, S) (the 45 per-position tap products, f32) */
 int fdet_mb_stem(const void* x, int x_is_u8, const float* w, const float* bias, void* y, int N, int H, int W, void* stream);
 int fdet_mb_depthwise(const void* x, const float* w, const float* bias, void* y, float* pool, int N, int H, int W, int C,
                       int K, int stride, int act, void* stream);
@@ -318,7 +320,9 @@ int fdet_mb_se_gate(const float* pool, int HW, const float* w1, const float* b1,
                     int C, int R, float* gate, void* stream);
 int fdet_mb_pointwise(const void* x, const void* w, const float* bias, const float* gate, const void* res, void* y, int N,
                       int P, int Cin, int Cout, int act, void* stream);
-int fdet_mb_head(const void* f, const float* w, const float* bias, float* y, int N, int S, int C, void* stream);
+size_t fdet_mb_head_ws_bytes(int N, int S);
+int fdet_mb_head(const void* f, const void* w, const float* bias, float* y, void* ws, size_t ws_bytes, int N, int S, int C,
+                 void* stream);
 
 /* Backward of the residual-block tail (dropout, skip, max-pool, second LeakyReLU):
  *   e = c*drop_scale + x ; out = maxpool(e) ; given dout [N,F,H/pool,W/pool]:

@@ -4,24 +4,33 @@
 // memory-bound (depthwise convs and thin 1x1 GEMMs: 2-30 FLOP/B), so every kernel is built around 16-byte channel-vector
 // accesses, reads each activation once and writes each once:
 //
-//   k_mb_stem      Conv2dSame(3,16,3,s2) + BN + Hardswish, NCHW f32 / u8 (the /255 fused) -> NHWC bf16
-//   k_mb_dw<K>     depthwise KxK (stride 1: pad K/2; stride 2: TF "SAME", the smaller half of the padding in front) + BN + act;
-//                  optionally the SqueezeExcite global-average-pool numerators (per image and channel) as a by-product
+//   k_mb_stem      Conv2dSame(3,16,3,s2) + BN + Hardswish, NCHW f32 / u8 (the /255 fused) -> NHWC bf16.  A workgroup stages the
+//                  5 input rows of 2 output rows in LDS with coalesced row loads (the stride-2 taps then come from LDS);
+//                  the 432 weights are wave-uniform scalar loads
+//   k_mb_dw<K,S,XS> depthwise KxK (stride 1: pad K/2; stride 2: TF "SAME", the smaller half of the padding in front) + BN + act.
+//                  A thread owns 8 channels x a strip of XS output columns: the (XS-1)S+K input columns of a row are loaded
+//                  once (branch-free: clamped address + select) and reused by the XS outputs.  Optionally the SqueezeExcite
+//                  global-average-pool numerators (per image and channel) as a by-product
 //   k_mb_se        SqueezeExcite gate: mean -> FC reduce + ReLU -> FC expand -> Hardsigmoid, one workgroup per image
-//   k_mb_pw<MT>    pointwise conv as a bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate): A = weights [Cout][Cin]
-//                  and B = activations [position][Cin] are both K-contiguous, so every fragment is one 16-byte global load
-//                  (no LDS, no transposes); the SE gate is applied to the B fragment, bias + activation + residual in the
-//                  epilogue
-//   k_mb_head      Conv2d(576,5,3,p1) + sigmoid -> NCHW f32 maps for the decode / NMS kernels of the YOLO path
+//   k_mb_pw<MT,WL> pointwise conv as a bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate): A = weights [Cout][Cin]
+//                  and B = activations [position][Cin] are both K-contiguous, so a fragment is one 16-byte load: B straight
+//                  from global, A from the workgroup's weight panel in LDS (WL; panels above 64 KB stay in L2).  The SE gate
+//                  is applied to the B fragment; bias + activation + residual in the epilogue, which pairs the half-waves'
+//                  4-channel groups with v_permlane32_swap so that every store is 16 bytes
+//   k_mb_head_*    Conv2d(576,5,3,p1) + sigmoid: per-position MFMA GEMM to the 45 (tap, channel) products (weights split into
+//                  bf16 hi + lo: fp32-grade products; the features are read once), then a 9-neighbour gather + bias + sigmoid
+//                  -> NCHW f32 maps for the decode / NMS kernels
 #include "fdet_conv3x3_x3.h"
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 using namespace fdet;
 
 namespace {
 
 typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 typedef u16 u16x4 __attribute__((ext_vector_type(4)));
@@ -35,105 +44,185 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 // ------------------------------------------------------------------------------------------------ stem
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const unsigned char* p) {
+  const unsigned v = *reinterpret_cast<const unsigned*>(p);
+  return float4{(float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24)};
+}
+
+// grid (ceil(Wo/256), ceil(Ho/2), N); thread = one output column, two output rows
 template <typename TIN>
 __global__ void __launch_bounds__(256)
 k_mb_stem(const TIN* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, u16* __restrict__ y,
-          int N, int H, int W, int Ho, int Wo, float in_scale) {
-  __shared__ float ws[16 * 27 + 16];
-  for (int t = threadIdx.x; t < 16 * 27; t += 256) ws[t] = w[t];
-  if (threadIdx.x < 16) ws[16 * 27 + threadIdx.x] = bias[threadIdx.x];
-  __syncthreads();
-  const size_t total = (size_t)N * Ho * Wo;
-  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
-    const int ox = (int)(t % Wo);
-    const size_t r = t / Wo;
-    const int oy = (int)(r % Ho), n = (int)(r / Ho);
-    float v[27];
+          int H, int W, int Ho, int Wo, float in_scale) {
+  constexpr int LW = 516;                                         // 2*256 + 1 input columns of a 256-column tile, padded
+  __shared__ __attribute__((aligned(16))) float in[3][5][LW];
+  const int n = blockIdx.z, oy0 = blockIdx.y * 2, ox0 = blockIdx.x * 256;
+  if ((W & 3) == 0) {
+    // 15 rows x 129 four-pixel groups, all of a thread's (up to 8) loads issued before the first LDS write: one memory
+    // latency per workgroup instead of one per row
+    constexpr int NV = LW / 4;
+    float4 val[8];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int iy = 2 * oy + ky, ix = 2 * ox + kx;            // TF SAME, even input: nothing on the top/left, one on the bottom/right
-          v[(c * 3 + ky) * 3 + kx] = (iy < H && ix < W) ? (float)x[(((size_t)n * 3 + c) * H + iy) * W + ix] * in_scale : 0.f;
-        }
-    u16 o[16];
-#pragma unroll
-    for (int co = 0; co < 16; ++co) {
-      float s = ws[16 * 27 + co];
-#pragma unroll
-      for (int k = 0; k < 27; ++k) s = fmaf(v[k], ws[co * 27 + k], s);
-      o[co] = f2bf(act_apply(s, 2));
+    for (int j = 0; j < 8; ++j) {
+      const int idx = threadIdx.x + 256 * j, r = idx / NV, c4 = idx - r * NV;
+      const int c = r / 5, iy = 2 * oy0 + (r - c * 5), col = 2 * ox0 + 4 * c4;
+      const bool ok = idx < 15 * NV && iy < H && col < W;          // W % 4 == 0: a group is all in or all out
+      val[j] = load4(x + (((size_t)n * 3 + (ok ? c : 0)) * H + (ok ? iy : 0)) * W + (ok ? col : 0));
+      if (!ok) val[j] = float4{0.f, 0.f, 0.f, 0.f};               // TF SAME: nothing in front, zeros behind the last row/column
     }
-    __builtin_memcpy(y + t * 16, o, 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = threadIdx.x + 256 * j, r = idx / NV, c4 = idx - r * NV;
+      if (idx < 15 * NV)
+        *reinterpret_cast<float4*>(&in[0][0][0] + r * LW + 4 * c4) =
+            float4{val[j].x * in_scale, val[j].y * in_scale, val[j].z * in_scale, val[j].w * in_scale};
+    }
+  } else {
+    const int ncol = min(2 * (Wo - ox0) + 1, 513);
+    for (int r = 0; r < 15; ++r) {
+      const int c = r / 5, iy = 2 * oy0 + (r - c * 5);
+      const TIN* __restrict__ src = x + (((size_t)n * 3 + c) * H + (iy < H ? iy : 0)) * W + 2 * ox0;
+      for (int t = threadIdx.x; t < ncol; t += 256)
+        in[c][r - c * 5][t] = (iy < H && 2 * ox0 + t < W) ? (float)src[t] * in_scale : 0.f;
+    }
   }
+  __syncthreads();
+  const int ox = ox0 + threadIdx.x;
+  if (ox >= Wo) return;
+  // the thread's two output rows ride in the two halves of packed fp32 FMAs (v_pk_fma_f32, the weight a broadcast SGPR)
+  f32x2v v[27];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        v[(c * 3 + ky) * 3 + kx].x = in[c][ky][2 * threadIdx.x + kx];
+        v[(c * 3 + ky) * 3 + kx].y = in[c][2 + ky][2 * threadIdx.x + kx];
+      }
+  u16 o[2][16];
+#pragma unroll
+  for (int co = 0; co < 16; ++co) {
+    const float b = bias[co];                                     // uniform addresses: scalar loads
+    f32x2v s = {b, b};
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const float wk = w[co * 27 + k];
+      s = __builtin_elementwise_fma(v[k], f32x2v{wk, wk}, s);
+    }
+    o[0][co] = f2bf(act_apply(s.x, 2));
+    o[1][co] = f2bf(act_apply(s.y, 2));
+  }
+  __builtin_memcpy(y + (((size_t)n * Ho + oy0) * Wo + ox) * 16, o[0], 32);
+  if (oy0 + 1 < Ho) __builtin_memcpy(y + (((size_t)n * Ho + oy0 + 1) * Wo + ox) * 16, o[1], 32);
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise
 struct DwArgs {
   const u16* x; const float* w; const float* bias; u16* y; float* pool;   // w: [K*K][C] folded; pool: [N][C] sums or null
-  int N, H, W, C, Ho, Wo, stride, pad, act;
+  int N, H, W, C, Ho, Wo, pad, act, strips;                               // strips = ceil(Wo / XS) per output row
+  int CW, IMG;                                                            // channels per workgroup (blockIdx.z chunk), images per workgroup
 };
 
-template <int K>
+// one input row of a strip: branch-free (always a valid address, zeros selected afterwards)
+template <int NC>
+__device__ __forceinline__ void dw_load_row(u16x8 (&v)[NC], const u16* __restrict__ xn, int iy, int ix0, int H, int W, int C) {
+  const bool rok = iy >= 0 && iy < H;
+  const u16* __restrict__ xr = xn + (size_t)(rok ? iy : 0) * W * C;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ix = ix0 + c;
+    const bool ok = rok && ix >= 0 && ix < W;
+    v[c] = *reinterpret_cast<const u16x8*>(xr + (size_t)(ok ? ix : 0) * C);
+    if (!ok) v[c] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+
+template <int K, int S, int XS>
 __global__ void __launch_bounds__(256)
 k_mb_dw(const DwArgs a) {
-  // one thread = one output position x 8 channels; threads of a workgroup: CG = C/8 channel groups fastest, then positions of
-  // ONE image (blockIdx.y = image), so the pooled sums of a workgroup go to one row of `pool`
-  extern __shared__ __attribute__((aligned(16))) float wl[];      // [K*K][C] weights, then [C] bias
-  const int C = a.C, CG = C >> 3;
-  for (int t = threadIdx.x; t < K * K * C; t += 256) wl[t] = a.w[t];
-  for (int t = threadIdx.x; t < C; t += 256) wl[K * K * C + t] = a.bias[t];
+  // one thread = 8 channels x XS adjacent output columns.  A workgroup owns a chunk of CW channels (blockIdx.z) whose
+  // K*K*CW weights sit in LDS, and walks IMG images (blockIdx.y) with them; its threads: CGW = CW/8 channel groups
+  // fastest, then strips of the image, so the pooled sums of one image's walk go to one row of `pool`
+  constexpr int NC = (XS - 1) * S + K;                            // input columns a strip reads per row
+  extern __shared__ __attribute__((aligned(16))) float wl[];      // [K*K][CW] weights, then [CW] bias, then the pool scratch
+  const int C = a.C, CW = a.CW, CGW = CW >> 3, c0 = blockIdx.z * CW;
+  for (int t = threadIdx.x; t < K * K * (CW >> 2); t += 256) {
+    const int tap = t / (CW >> 2), c4 = t - tap * (CW >> 2);
+    *reinterpret_cast<float4*>(wl + tap * CW + c4 * 4) = *reinterpret_cast<const float4*>(a.w + (size_t)tap * C + c0 + c4 * 4);
+  }
+  for (int t = threadIdx.x; t < CW; t += 256) wl[K * K * CW + t] = a.bias[c0 + t];
   __syncthreads();
-  const int n = blockIdx.y;
-  const int per_wg = 256 / CG;                                    // positions per workgroup pass (CG <= 72 -> >= 3)
-  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
-  const int npos = a.Ho * a.Wo;
-  float psum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (pl < per_wg) {
-    for (int p = blockIdx.x * per_wg + pl; p < npos; p += gridDim.x * per_wg) {
-      const int oy = p / a.Wo, ox = p - oy * a.Wo;
-      float acc[8];
+  const int per_wg = 256 / CGW;                                   // strips per workgroup pass (CGW <= 72 -> >= 3)
+  const int cg = threadIdx.x % CGW, pl = threadIdx.x / CGW;
+  const int nitems = a.Ho * a.strips;
+  float* part = wl + K * K * CW + CW;                             // [256][8]
+  for (int im = 0; im < a.IMG; ++im) {
+    const int n = blockIdx.y * a.IMG + im;
+    if (n >= a.N) break;                                          // uniform over the workgroup
+    const u16* __restrict__ xn = a.x + (size_t)n * a.H * a.W * C + c0 + cg * 8;
+    float psum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (pl < per_wg) {
+      for (int it = blockIdx.x * per_wg + pl; it < nitems; it += gridDim.x * per_wg) {
+        const int oy = it / a.strips, ox0 = (it - oy * a.strips) * XS;
+        // channel pairs ride in packed fp32 FMAs (v_pk_fma_f32): acc[q][h] = channels 2h, 2h+1 of output column q
+        f32x2v acc[XS][4];
+        {
+          const f32x2v* bp = reinterpret_cast<const f32x2v*>(wl + K * K * CW + cg * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = wl[K * K * C + cg * 8 + j];
+          for (int q = 0; q < XS; ++q)
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        const int iy = oy * a.stride - a.pad + ky;
-        if (iy < 0 || iy >= a.H) continue;
+            for (int h = 0; h < 4; ++h) acc[q][h] = bp[h];
+        }
+#pragma unroll 1                                                  // one row of taps at a time: ~120 VGPRs, 4 waves per SIMD hide the loads
+        for (int ky = 0; ky < K; ++ky) {
+          u16x8 v[NC];
+          dw_load_row<NC>(v, xn, oy * S - a.pad + ky, ox0 * S - a.pad, a.H, a.W, C);
+          f32x2v xv[NC][4];
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-          const int ix = ox * a.stride - a.pad + kx;
-          if (ix < 0 || ix >= a.W) continue;
-          const u16x8 v = *reinterpret_cast<const u16x8*>(a.x + (((size_t)n * a.H + iy) * a.W + ix) * C + cg * 8);
-          const float* wt = wl + (ky * K + kx) * C + cg * 8;
+          for (int c = 0; c < NC; ++c)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] = fmaf(bf2f(v[j]), wt[j], acc[j]);
+            for (int h = 0; h < 4; ++h) xv[c][h] = f32x2v{bf2f(v[c][2 * h]), bf2f(v[c][2 * h + 1])};
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            const f32x2v* wt = reinterpret_cast<const f32x2v*>(wl + (ky * K + kx) * CW + cg * 8);
+            f32x2v wv[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) wv[h] = wt[h];
+#pragma unroll
+            for (int q = 0; q < XS; ++q)
+#pragma unroll
+              for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(xv[q * S + kx][h], wv[h], acc[q][h]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < XS; ++q) {
+          if (ox0 + q >= a.Wo) break;
+          u16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            o[j] = f2bf(act_apply(acc[q][j >> 1][j & 1], a.act));
+            psum[j] += bf2f(o[j]);                                // the pool sees what the next layer reads
+          }
+          *reinterpret_cast<u16x8*>(a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox0 + q) * C + c0 + cg * 8) = o;
         }
       }
-      u16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float r = act_apply(acc[j], a.act);
-        o[j] = f2bf(r);
-        psum[j] += bf2f(o[j]);                                    // the pool sees what the next layer reads
-      }
-      *reinterpret_cast<u16x8*>(a.y + ((size_t)n * npos + p) * C + cg * 8) = o;
     }
-  }
-  if (a.pool) {
-    // SqueezeExcite numerators: fixed-order sum over this workgroup's positions per channel (LDS), then ONE float atomic
-    // per (workgroup, channel) -- the only order-dependent step (differences ~1 ulp of an fp32 mean that is then read
-    // through a hardsigmoid and a bf16 product)
-    float* part = wl + K * K * C + C;                             // [256][8]
+    if (a.pool) {
+      // SqueezeExcite numerators: fixed-order sum over this workgroup's threads per channel (LDS), then ONE float atomic
+      // per (workgroup, image, channel) -- the only order-dependent step (differences ~1 ulp of an fp32 mean that is
+      // then read through a hardsigmoid and a bf16 product)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) part[threadIdx.x * 8 + j] = (pl < per_wg) ? psum[j] : 0.f;
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-      const int g = c >> 3, j = c & 7;
-      float s = 0.f;
-      for (int q = 0; q < per_wg; ++q) s += part[(q * CG + g) * 8 + j];
-      atomicAdd(a.pool + (size_t)n * C + c, s);
+      for (int j = 0; j < 8; ++j) part[threadIdx.x * 8 + j] = (pl < per_wg) ? psum[j] : 0.f;
+      __syncthreads();
+      for (int c = threadIdx.x; c < CW; c += 256) {
+        const int g = c >> 3, j = c & 7;
+        float s = 0.f;
+        for (int q = 0; q < per_wg; ++q) s += part[(q * CGW + g) * 8 + j];
+        atomicAdd(a.pool + (size_t)n * C + c0 + c, s);
+      }
+      __syncthreads();                                            // `part` is rewritten for the next image
     }
   }
 }
@@ -170,14 +259,25 @@ struct PwmArgs {
   int N, P, Cin, CiP, Cout, tiles_per_img, act;
 };
 
-template <int MT>
+template <int MT, bool WL, bool ST, int KU>
 __global__ void __launch_bounds__(256)
 k_mb_pw(const PwmArgs a) {
+  // WL: [MT*32][CiP + 8] weight panel (row stride = odd number of 16-byte units); ST: then 4 x [32][MT*32 + 8] output staging
+  extern __shared__ __attribute__((aligned(16))) u16 wpan[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int n = blockIdx.x / a.tiles_per_img;
   const int p = (blockIdx.x - n * a.tiles_per_img) * 128 + wid * 32 + l31;      // this lane's position (B column)
   const int cob = blockIdx.y * (MT * 32);
+  const int LS = a.CiP + 8;
+  if (WL) {
+    const int cpr = a.CiP >> 3;                                   // 16-byte chunks per weight row
+    for (int t = threadIdx.x; t < MT * 32 * cpr; t += 256) {
+      const int r = t / cpr, c = t - r * cpr;
+      *reinterpret_cast<u16x8*>(wpan + r * LS + c * 8) = *reinterpret_cast<const u16x8*>(a.w + (size_t)(cob + r) * a.CiP + c * 8);
+    }
+    __syncthreads();
+  }
   const bool pok = p < a.P;
   const u16* __restrict__ xr = a.x + ((size_t)n * a.P + (pok ? p : 0)) * a.Cin;
   const float* __restrict__ gr = a.gate ? a.gate + (size_t)n * a.Cin : nullptr;
@@ -186,75 +286,184 @@ k_mb_pw(const PwmArgs a) {
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-  for (int k0 = 0; k0 < a.CiP; k0 += 16) {
-    const int k = k0 + 8 * half;
-    u16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (pok && k < a.Cin) b = *reinterpret_cast<const u16x8*>(xr + k);
-    if (gr && k < a.Cin) {
+  for (int k0 = 0; k0 < a.CiP; k0 += 16 * KU) {
+    // KU k-steps of operand loads issued together (KU = 4 for Cin >= 128: one memory latency per 64 input channels)
+    u16x8 b[KU];
+    float4 g0[KU], g1[KU];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) b[j] = f2bf(bf2f(b[j]) * gr[k + j]);
+    for (int u = 0; u < KU; ++u) {
+      const int k = k0 + 16 * u + 8 * half;
+      const bool kok = k < a.Cin;                                 // Cin % 8 == 0: a group of 8 is all in or all out
+      b[u] = *reinterpret_cast<const u16x8*>(xr + (kok ? k : 0));
+      if (!(pok && kok)) b[u] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (gr) {
+        g0[u] = *reinterpret_cast<const float4*>(gr + (kok ? k : 0));
+        g1[u] = *reinterpret_cast<const float4*>(gr + (kok ? k : 0) + 4);
+      }
     }
-    const bf16x8 bf = __builtin_bit_cast(bf16x8, b);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(cob + m * 32 + l31) * a.CiP + k);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[m], 0, 0, 0);
+    for (int u = 0; u < KU; ++u) {
+      if (KU > 1 && k0 + 16 * u >= a.CiP) break;                  // uniform
+      const int k = k0 + 16 * u + 8 * half;
+      if (gr) {
+        const float gv[8] = {g0[u].x, g0[u].y, g0[u].z, g0[u].w, g1[u].x, g1[u].y, g1[u].z, g1[u].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[u][j] = f2bf(bf2f(b[u][j]) * gv[j]);
+      }
+      const bf16x8 bf = __builtin_bit_cast(bf16x8, b[u]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const bf16x8 af = WL ? *reinterpret_cast<const bf16x8*>(wpan + (m * 32 + l31) * LS + k)
+                             : *reinterpret_cast<const bf16x8*>(a.w + (size_t)(cob + m * 32 + l31) * a.CiP + k);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[m], 0, 0, 0);
+      }
     }
   }
-  if (!pok) return;
   // acc[m][r]: column = this lane's position, row (output channel) = cob + 32m + (r&3) + 8(r>>2) + 4half
-  u16* __restrict__ yr = a.y + ((size_t)n * a.P + p) * a.Cout;
-  const u16* __restrict__ rr = a.res ? a.res + ((size_t)n * a.P + p) * a.Cout : nullptr;
+  const size_t row = ((size_t)n * a.P + (pok ? p : 0)) * a.Cout;
+  if (ST) {
+    // the wave's 32 positions x MT*32 channels go through LDS so that the stores walk memory contiguously (a position's
+    // channels are contiguous, and so are consecutive positions when the workgroup covers all of Cout)
+    constexpr int SS = MT * 32 + 8;
+    u16* stg = wpan + (WL ? MT * 32 * LS : 0) + wid * 32 * SS;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = cob + 32 * m + 8 * g + 4 * half;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = act_apply(acc[m][4 * g + i] + a.bias[ch + i], a.act);   // bias padded to CoP: always readable
+        if (a.res && pok && ch < a.Cout) {
+          const u16x4 rv = *reinterpret_cast<const u16x4*>(a.res + row + ch);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += bf2f(rv[i]);
+        }
+        uint2 o;
+        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(stg + l31 * SS + 32 * m + 8 * g + 4 * half) = o;
+      }
+    __syncthreads();
+    const int cw = min(MT * 32, a.Cout - cob), cpr = cw >> 3;     // 16-byte chunks per position
+    const int p0 = (blockIdx.x - n * a.tiles_per_img) * 128 + wid * 32;
+    u16* __restrict__ yb = a.y + ((size_t)n * a.P + p0) * a.Cout + cob;
+    for (int idx = lane; idx < 32 * cpr; idx += 64) {
+      const int r = idx / cpr, c = idx - r * cpr;
+      if (p0 + r < a.P) *reinterpret_cast<uint4*>(yb + (size_t)r * a.Cout + c * 8) = *reinterpret_cast<const uint4*>(stg + r * SS + c * 8);
+    }
+    return;
+  }
+  // direct stores: the half-waves exchange 4-channel groups (v_permlane32_swap) so that the lower half owns channels
+  // 16q..16q+7 and the upper half 16q+8..16q+15 of the position: one 16-byte store each
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = cob + 32 * m + 8 * g + 4 * half;
-      if (co >= a.Cout) continue;                                 // Cout % 8 == 0: a group of 4 is all in or all out
-      u16x4 rv = {0, 0, 0, 0};
-      if (rr) rv = *reinterpret_cast<const u16x4*>(rr + co);
-      u16x4 o;
+    for (int q = 0; q < 2; ++q) {
+      const int co = cob + 32 * m + 16 * q + 8 * half;            // first of this lane's 8 channels after the exchange
+      unsigned pk[2][2];                                          // [group 2q, 2q+1][two packed bf16 pairs] before the exchange
+      float v[2][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = act_apply(acc[m][4 * g + i] + a.bias[co + i], a.act);
-        if (rr) v += bf2f(rv[i]);
-        o[i] = f2bf(v);
+      for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ch = cob + 32 * m + 8 * (2 * q + gq) + 4 * half + i;
+          v[gq][i] = act_apply(acc[m][4 * (2 * q + gq) + i] + a.bias[ch], a.act);
+        }
+      if (a.res) {
+        // the residual is added BEFORE the exchange, in this lane's own (pre-exchange) channel groups
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+          const int ch = cob + 32 * m + 8 * (2 * q + gq) + 4 * half;
+          if (pok && ch < a.Cout) {
+            const u16x4 rv = *reinterpret_cast<const u16x4*>(a.res + row + ch);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[gq][i] += bf2f(rv[i]);
+          }
+        }
       }
-      *reinterpret_cast<u16x4*>(yr + co) = o;
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        pk[gq][0] = (unsigned)f2bf(v[gq][0]) | ((unsigned)f2bf(v[gq][1]) << 16);
+        pk[gq][1] = (unsigned)f2bf(v[gq][2]) | ((unsigned)f2bf(v[gq][3]) << 16);
+      }
+      const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+      if (pok && co < a.Cout) {                                   // Cout % 8 == 0: 8 channels all in or all out
+        uint4 o; o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+        *reinterpret_cast<uint4*>(a.y + row + co) = o;
+      }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ head
-// Conv2d(C,5,3,p1) + sigmoid on the S x S feature map: one workgroup per (image, output position); threads split the
-// 9*C products, fixed-order LDS reduction.  Output NCHW f32 (what fdet_reduce_bounding_boxes reads).
+// Conv2d(C,5,3,p1) + sigmoid on the S x S map.  The conv is linear, so it is computed as (1) a per-position GEMM
+// g[q][tap*5 + ch] = W[ch][tap] . f[q] -- the features are read ONCE, 45 outputs per position in two 32-row tiles, weights
+// bf16 hi + lo (two MFMAs per tile and step: the products carry ~16 mantissa bits of the fp32 weight) -- and (2) a gather
+// y[ch][pos] = sigmoid(bias + sum over the 9 taps of g[pos + tap offset][tap*5 + ch]), zeros outside the map.
+// w: [2][64][C] bf16 (hi, lo; rows 45..63 zero), g: [total][48] f32.
 __global__ void __launch_bounds__(256)
-k_mb_head(const u16* __restrict__ f, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-          int N, int S, int C) {
-  __shared__ float part[5][256];
-  const int pos = blockIdx.x % (S * S), n = blockIdx.x / (S * S);
-  const int oy = pos / S, ox = pos - oy * S;
-  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int t = threadIdx.x; t < 9 * C; t += 256) {
-    const int tap = t / C, c = t - tap * C;
+k_mb_head_gemm(const u16* __restrict__ f, const u16* __restrict__ w, float* __restrict__ g, int total, int C) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int q = blockIdx.x * 128 + wid * 32 + l31;
+  const bool qok = q < total;
+  const u16* __restrict__ fr = f + (size_t)(qok ? q : 0) * C + 8 * half;
+  const u16* __restrict__ w0 = w + (size_t)l31 * C + 8 * half;               // tile 0 row; tile 1 = +32 rows; lo = +64 rows
+  f32x16v acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  for (int k0 = 0; k0 < C; k0 += 32) {
+    u16x8 b[2], ah[2][2], al[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = min(k0 + 16 * u, C - 16);                     // C % 16 == 0; a step past the end is loaded but not used
+      b[u] = *reinterpret_cast<const u16x8*>(fr + k);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        ah[u][m] = *reinterpret_cast<const u16x8*>(w0 + (size_t)(32 * m) * C + k);
+        al[u][m] = *reinterpret_cast<const u16x8*>(w0 + (size_t)(64 + 32 * m) * C + k);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (k0 + 16 * u >= C) break;
+      if (!qok) b[u] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      const bf16x8 bf = __builtin_bit_cast(bf16x8, b[u]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[u][m]), bf, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[u][m]), bf, acc[m], 0, 0, 0);
+      }
+    }
+  }
+  if (!qok) return;
+  // acc[m][4g + i]: row 32m + 8g + 4half + i of this lane's position; rows < 48 are stored (45..47 are zeros)
+  float* __restrict__ gq = g + (size_t)q * 48;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const int row = 32 * m + 8 * gi + 4 * half;
+      if (row < 48) *reinterpret_cast<float4*>(gq + row) = float4{acc[m][4 * gi], acc[m][4 * gi + 1], acc[m][4 * gi + 2], acc[m][4 * gi + 3]};
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_mb_head_gather(const float* __restrict__ g, const float* __restrict__ bias, float* __restrict__ y, int total, int S) {
+  const int t = blockIdx.x * 256 + threadIdx.x;                   // one thread per (position, channel)
+  if (t >= total * 5) return;
+  const int q = t / 5, ch = t - q * 5;
+  const int n = q / (S * S), pos = q - n * S * S, oy = pos / S, ox = pos - oy * S;
+  float z = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {                             // fixed tap order
     const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-    if (iy < 0 || iy >= S || ix < 0 || ix >= S) continue;
-    const float v = bf2f(f[(((size_t)n * S + iy) * S + ix) * C + c]);
-#pragma unroll
-    for (int o = 0; o < 5; ++o) s[o] = fmaf(v, w[((size_t)o * 9 + tap) * C + c], s[o]);   // w: [5][9][C]
+    if (iy >= 0 && iy < S && ix >= 0 && ix < S) z += g[((size_t)(n * S + iy) * S + ix) * 48 + tap * 5 + ch];
   }
-#pragma unroll
-  for (int o = 0; o < 5; ++o) part[o][threadIdx.x] = s[o];
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if ((int)threadIdx.x < st)
-#pragma unroll
-      for (int o = 0; o < 5; ++o) part[o][threadIdx.x] += part[o][threadIdx.x + st];
-    __syncthreads();
-  }
-  if (threadIdx.x < 5) {
-    const float z = part[threadIdx.x][0] + bias[threadIdx.x];
-    y[(((size_t)n * 5 + threadIdx.x) * S + oy) * S + ox] = 1.f / (1.f + expf(-z));
-  }
+  y[((size_t)n * 5 + ch) * S * S + pos] = 1.f / (1.f + expf(-(z + bias[ch])));
 }
 
 }  // namespace
@@ -262,41 +471,57 @@ k_mb_head(const u16* __restrict__ f, const float* __restrict__ w, const float* _
 extern "C" int fdet_mb_stem(const void* x, int x_is_u8, const float* w, const float* bias, void* y, int N, int H, int W,
                             void* stream) {
   FDET_REQUIRE(x && w && bias && y && N > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1), "mb_stem: bad arguments (even H, W)");
+  FDET_REQUIRE(N <= 65535 && H / 4 + 1 <= 65535, "mb_stem: batch or height beyond the launch grid");
   const int Ho = H / 2, Wo = W / 2;
-  const size_t total = (size_t)N * Ho * Wo;
-  size_t blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
-  if (x_is_u8) hipLaunchKernelGGL(k_mb_stem<unsigned char>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x, w, bias, (u16*)y, N, H, W, Ho, Wo, 1.0f / 255.0f);
-  else hipLaunchKernelGGL(k_mb_stem<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, bias, (u16*)y, N, H, W, Ho, Wo, 1.0f);
+  dim3 grid((Wo + 255) / 256, (Ho + 1) / 2, N);
+  if (x_is_u8) hipLaunchKernelGGL(k_mb_stem<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x, w, bias, (u16*)y, H, W, Ho, Wo, 1.0f / 255.0f);
+  else hipLaunchKernelGGL(k_mb_stem<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, w, bias, (u16*)y, H, W, Ho, Wo, 1.0f);
   return check_launch("fdet_mb_stem");
+}
+
+template <int K, int S, int XS>
+static int launch_dw(DwArgs a, hipStream_t st) {
+  a.strips = (a.Wo + XS - 1) / XS;
+  // channel chunks of at most 192 (28 KB of LDS with 5x5 taps: 5 workgroups per CU); the chunk must be a multiple of 8
+  int nchunk = (a.C + 191) / 192;
+  while (nchunk < a.C / 8 && a.C % (8 * nchunk)) ++nchunk;
+  a.CW = a.C / nchunk;
+  const int CGW = a.CW / 8, per_wg = 256 / CGW;
+  const int passes = (a.Ho * a.strips + per_wg - 1) / per_wg;     // workgroup passes over one image's strips
+  // ~4096 workgroups for the whole launch; beyond that a workgroup takes several passes, then several images, with one
+  // fill of its weights
+  const long long total = (long long)a.N * nchunk * passes;
+  const int ppw = (int)std::max(1LL, total / 4096);
+  const int bx = (passes + std::min(ppw, passes) - 1) / std::min(ppw, passes);
+  a.IMG = std::min(std::max(1, ppw / passes), 64);
+  const size_t lds = ((size_t)K * K * a.CW + a.CW + 256 * 8) * sizeof(float);
+  static bool attr_done = false;                                  // per instantiation
+  if (!attr_done) {
+    FDET_REQUIRE(hipFuncSetAttribute((const void*)k_mb_dw<K, S, XS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess, "mb_depthwise: LDS");
+    attr_done = true;
+  }
+  FDET_REQUIRE(lds <= 80 * 1024, "mb_depthwise: channel chunk does not fit LDS");
+  hipLaunchKernelGGL((k_mb_dw<K, S, XS>), dim3(bx, (a.N + a.IMG - 1) / a.IMG, nchunk), dim3(256), lds, st, a);
+  return check_launch("fdet_mb_depthwise");
 }
 
 extern "C" int fdet_mb_depthwise(const void* x, const float* w, const float* bias, void* y, float* pool, int N, int H, int W,
                                  int C, int K, int stride, int act, void* stream) {
-  FDET_REQUIRE(x && w && bias && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 576 && (K == 3 || K == 5) &&
+  FDET_REQUIRE(x && w && bias && y && N > 0 && N <= 65535 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 576 && (K == 3 || K == 5) &&
                (stride == 1 || stride == 2) && act >= 0 && act <= 2, "mb_depthwise: bad arguments (C %% 8 == 0, C <= 576, K 3|5, stride 1|2)");
   DwArgs a;
   a.x = (const u16*)x; a.w = w; a.bias = bias; a.y = (u16*)y; a.pool = pool;
-  a.N = N; a.H = H; a.W = W; a.C = C; a.stride = stride; a.act = act;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.act = act;
   a.Ho = (H + stride - 1) / stride; a.Wo = (W + stride - 1) / stride;
   // stride 1: symmetric K/2.  stride 2: TF "SAME": total = max((Ho-1)*2 + K - H, 0), the smaller half in front
   a.pad = stride == 1 ? K / 2 : std::max((a.Ho - 1) * 2 + K - H, 0) / 2;
   if (stride == 2) FDET_REQUIRE(H == W, "mb_depthwise: stride-2 layers need square maps (one pad value for both axes)");
   if (pool) (void)hipMemsetAsync(pool, 0, (size_t)N * C * sizeof(float), (hipStream_t)stream);
-  const int CG = C / 8, per_wg = 256 / CG;
-  const int npos = a.Ho * a.Wo;
-  int bx = (npos + per_wg - 1) / per_wg;
-  const int cap = std::max(1, 4096 / N);
-  if (bx > cap) bx = cap;
-  const size_t lds = ((size_t)K * K * C + C + 256 * 8) * sizeof(float);
-  dim3 grid(bx, N);
-  if (K == 3) {
-    FDET_REQUIRE(hipFuncSetAttribute((const void*)k_mb_dw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "mb_depthwise: LDS");
-    hipLaunchKernelGGL(k_mb_dw<3>, grid, dim3(256), lds, (hipStream_t)stream, a);
-  } else {
-    FDET_REQUIRE(hipFuncSetAttribute((const void*)k_mb_dw<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "mb_depthwise: LDS");
-    hipLaunchKernelGGL(k_mb_dw<5>, grid, dim3(256), lds, (hipStream_t)stream, a);
-  }
-  return check_launch("fdet_mb_depthwise");
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 3 && stride == 1) return launch_dw<3, 1, 4>(a, st);
+  if (K == 3) return launch_dw<3, 2, 2>(a, st);
+  if (stride == 1) return launch_dw<5, 1, 4>(a, st);
+  return launch_dw<5, 2, 2>(a, st);
 }
 
 extern "C" int fdet_mb_se_gate(const float* pool, int HW, const float* w1, const float* b1, const float* w2, const float* b2,
@@ -304,6 +529,36 @@ extern "C" int fdet_mb_se_gate(const float* pool, int HW, const float* w1, const
   FDET_REQUIRE(pool && w1 && b1 && w2 && b2 && gate && N > 0 && C > 0 && C <= 576 && R > 0 && R <= 160 && HW > 0, "mb_se_gate: bad arguments");
   hipLaunchKernelGGL(k_mb_se, dim3(N), dim3(256), 0, (hipStream_t)stream, pool, 1.0f / (float)HW, w1, b1, w2, b2, C, R, gate);
   return check_launch("fdet_mb_se_gate");
+}
+
+template <int MT, bool WL, bool ST, int KU>
+static int launch_pw3(const PwmArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done && lds) {
+    FDET_REQUIRE(hipFuncSetAttribute((const void*)k_mb_pw<MT, WL, ST, KU>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess, "mb_pointwise: LDS");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_mb_pw<MT, WL, ST, KU>), grid, dim3(256), lds, st, a);
+  return check_launch("fdet_mb_pointwise");
+}
+
+template <int MT, bool WL, bool ST>
+static int launch_pw2(const PwmArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  return a.CiP >= 128 ? launch_pw3<MT, WL, ST, 4>(a, grid, lds, st) : launch_pw3<MT, WL, ST, 1>(a, grid, lds, st);
+}
+
+template <int MT>
+static int launch_pw(const PwmArgs& a, dim3 grid, hipStream_t st) {
+  // LDS budget 72 KB (2 workgroups per CU): the weight panel first (above 64 KB it stays in L2), then the output staging
+  static const int no_stage = std::getenv("FDET_MB_PW_STAGE") ? !std::atoi(std::getenv("FDET_MB_PW_STAGE")) : 0;
+  const size_t panel = (size_t)MT * 32 * (a.CiP + 8) * sizeof(u16);
+  const size_t stage = (size_t)4 * 32 * (MT * 32 + 8) * sizeof(u16);
+  const bool wl = panel <= 64 * 1024;
+  const bool stg = !no_stage && (wl ? panel : 0) + stage <= 72 * 1024;
+  if (wl && stg) return launch_pw2<MT, true, true>(a, grid, panel + stage, st);
+  if (wl) return launch_pw2<MT, true, false>(a, grid, panel, st);
+  if (stg) return launch_pw2<MT, false, true>(a, grid, stage, st);
+  return launch_pw2<MT, false, false>(a, grid, 0, st);
 }
 
 extern "C" int fdet_mb_pointwise(const void* x, const void* w, const float* bias, const float* gate, const void* res, void* y,
@@ -315,20 +570,32 @@ extern "C" int fdet_mb_pointwise(const void* x, const void* w, const float* bias
   a.N = N; a.P = P; a.Cin = Cin; a.CiP = (Cin + 15) / 16 * 16; a.Cout = Cout; a.act = act;
   a.tiles_per_img = (P + 127) / 128;
   const int CoT = (Cout + 31) / 32;                               // 32-channel row tiles of the (zero padded) weight panel
-  const int MT = CoT >= 6 && CoT % 6 == 0 ? 6 : (CoT % 4 == 0 ? 4 : (CoT % 3 == 0 ? 3 : (CoT % 2 == 0 ? 2 : 1)));
+  // one workgroup covers all output channels when it can (the input is then read once): up to 6 tiles = 192 channels (more costs occupancy: 9 tiles need 300 VGPRs)
+  int MT = 1;
+  for (int m : {6, 5, 4, 3, 2}) if (CoT % m == 0) { MT = m; break; }
+  FDET_REQUIRE((size_t)N * a.tiles_per_img < 0x7fffffffu, "mb_pointwise: too many position tiles");
   dim3 grid((unsigned)((size_t)N * a.tiles_per_img), CoT / MT);
+  hipStream_t st = (hipStream_t)stream;
   switch (MT) {
-    case 6: hipLaunchKernelGGL(k_mb_pw<6>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 4: hipLaunchKernelGGL(k_mb_pw<4>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 3: hipLaunchKernelGGL(k_mb_pw<3>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL(k_mb_pw<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    default: hipLaunchKernelGGL(k_mb_pw<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 6: return launch_pw<6>(a, grid, st);
+    case 5: return launch_pw<5>(a, grid, st);
+    case 4: return launch_pw<4>(a, grid, st);
+    case 3: return launch_pw<3>(a, grid, st);
+    case 2: return launch_pw<2>(a, grid, st);
+    default: return launch_pw<1>(a, grid, st);
   }
-  return check_launch("fdet_mb_pointwise");
 }
 
-extern "C" int fdet_mb_head(const void* f, const float* w, const float* bias, float* y, int N, int S, int C, void* stream) {
-  FDET_REQUIRE(f && w && bias && y && N > 0 && S > 0 && C > 0, "mb_head: bad arguments");
-  hipLaunchKernelGGL(k_mb_head, dim3((unsigned)((size_t)N * S * S)), dim3(256), 0, (hipStream_t)stream, (const u16*)f, w, bias, y, N, S, C);
+extern "C" size_t fdet_mb_head_ws_bytes(int N, int S) { return N > 0 && S > 0 ? (size_t)N * S * S * 48 * sizeof(float) : 0; }
+
+extern "C" int fdet_mb_head(const void* f, const void* w, const float* bias, float* y, void* ws, size_t ws_bytes, int N, int S,
+                            int C, void* stream) {
+  FDET_REQUIRE(f && w && bias && y && ws && N > 0 && S > 0 && C > 0 && C % 16 == 0 && (size_t)N * S * S * 5 < 0x7fffffffu,
+               "mb_head: bad arguments (C %% 16 == 0)");
+  FDET_REQUIRE(ws_bytes >= fdet_mb_head_ws_bytes(N, S), "mb_head: workspace smaller than fdet_mb_head_ws_bytes()");
+  const int total = N * S * S;
+  hipLaunchKernelGGL(k_mb_head_gemm, dim3((total + 127) / 128), dim3(256), 0, (hipStream_t)stream, (const u16*)f, (const u16*)w, (float*)ws, total, C);
+  FDET_REQUIRE(check_launch("fdet_mb_head") == 0, "mb_head: gemm launch failed");
+  hipLaunchKernelGGL(k_mb_head_gather, dim3((total * 5 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws, bias, y, total, S);
   return check_launch("fdet_mb_head");
 }

@@ -685,6 +685,7 @@ def mb_depthwise(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, K: int, s
 
 
 def mb_se_gate(pool: torch.Tensor, HW: int, w1, b1, w2, b2) -> torch.Tensor:
+    """gate (N,C) = hardsigmoid(W2 relu(W1 pool/HW + b1) + b2); w1 (R,C), w2 (C,R)."""
     Nn, C = pool.shape
     R = w1.shape[0]
     _chk4(w1, (R, C), "se reduce weight"); _chk4(b1, (R,), "se reduce bias")
@@ -722,12 +723,27 @@ def mb_pointwise(x: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, cout: int,
     return y
 
 
-def mb_head(f: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    """f (N,S,S,C) bf16 -> sigmoid(Conv2d(C,5,3,p1)) as (N,5,S,S) f32; w (5,9,C) f32."""
-    if f.dim() != 4 or f.dtype != BF16 or f.shape[1] != f.shape[2]:
-        raise ValueError("mb_head: expected (N,S,S,C) bf16")
+def mb_head_pack(w: torch.Tensor) -> torch.Tensor:
+    """Conv2d(C,5,3,p1) weight (5,C,3,3) f32 -> bf16 (2,64,C): row tap*5 + ch (rows 45..63 zero), split into
+    hi = bf16(w), lo = bf16(w - hi)."""
+    C = w.shape[1]
+    wt = torch.zeros(64, C, dtype=F32, device=w.device)
+    wt[:45] = w.float().permute(2, 3, 0, 1).reshape(45, C)       # (ky, kx, ch) -> tap*5 + ch
+    hi = wt.to(BF16)
+    lo = (wt - hi.float()).to(BF16)
+    return torch.stack([hi, lo]).contiguous()
+
+
+def mb_head(f: torch.Tensor, w2: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """f (N,S,S,C) bf16 -> sigmoid(Conv2d(C,5,3,p1)) as (N,5,S,S) f32; w2 = mb_head_pack(weight)."""
+    if f.dim() != 4 or f.dtype != BF16 or f.shape[1] != f.shape[2] or f.shape[3] % 16:
+        raise ValueError("mb_head: expected (N,S,S,C) bf16 with C % 16 == 0")
     Nn, S, _, C = f.shape
-    _chk4(w, (5, 9, C), "head weight"); _chk4(bias, (5,), "head bias")
+    if tuple(w2.shape) != (2, 64, C) or w2.dtype != BF16:
+        raise ValueError(f"mb_head: expected the packed weight (2,64,{C}) bf16, got {tuple(w2.shape)} {w2.dtype}")
+    _chk4(bias, (5,), "head bias")
     y = torch.empty(Nn, 5, S, S, dtype=F32, device=f.device)
-    check(lib().fdet_mb_head(ptr(f, BF16), ptr(w), ptr(bias), ptr(y), Nn, S, C, stream()), "fdet_mb_head")
+    nb = int(lib().fdet_mb_head_ws_bytes(Nn, S))
+    ws = torch.empty(nb // 4, dtype=F32, device=f.device)
+    check(lib().fdet_mb_head(ptr(f, BF16), ptr(w2, BF16), ptr(bias), ptr(y), ptr(ws), nb, Nn, S, C, stream()), "fdet_mb_head")
     return y

@@ -83,7 +83,7 @@ class MobileNetStack:
             L.append(e)
         w, b = _fold(P["feature_extractor.3.5.0.conv.weight"], P, "feature_extractor.3.5.0.bn1")
         final = hp.mb_pointwise_pack(w.reshape(FEATURES, 96), b)
-        head = (P["out.weight"].float().permute(0, 2, 3, 1).reshape(5, 9, FEATURES).contiguous(), P["out.bias"].float().contiguous())
+        head = (hp.mb_head_pack(P["out.weight"]), P["out.bias"].float().contiguous())
         self.packed = (stem, L, final, head)
 
     # ------------------------------------------------------------------ forward

@@ -122,7 +122,7 @@ def test_head(hp):
     f = _bf(torch.randn(N, C, S, S, generator=g))
     w = torch.randn(5, C, 3, 3, generator=g) * 0.02
     b = torch.randn(5, generator=g)
-    y = hp.mb_head(f.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda(), w.permute(0, 2, 3, 1).reshape(5, 9, C).contiguous().cuda(), b.cuda())
+    y = hp.mb_head(f.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda(), hp.mb_head_pack(w.cuda()), b.cuda())
     want = torch.sigmoid(F.conv2d(f, w, b, padding=1))
     assert torch.allclose(y.cpu(), want, rtol=1e-4, atol=1e-5), float((y.cpu() - want).abs().max())
 
