@@ -132,8 +132,11 @@ class ConvStack:
         self.pool_fusion = self.x3 and os.environ.get("FDET_POOL_FUSION", "1") != "0"
         # weight gradients on a second HIP stream: they depend only on tensors the data-gradient chain has already
         # produced, so the batched weight-gradient launch of one resolution runs beside the data-gradient kernels of the
-        # next (and the last one beside the stem's); joined before anything reads the gradients (FDET_WGRAD_STREAM=0: off)
-        self.wgrad_stream = os.environ.get("FDET_WGRAD_STREAM", "1") != "0"
+        # next (and the last one beside the stem's); joined before anything reads the gradients.  Opt-in
+        # (FDET_WGRAD_STREAM=1): measured -0.6 % per step only -- both kernel families are bound by the same HBM/MFMA
+        # resources, so they mostly slow each other down -- and overlapping launches make per-kernel timings (HIP events,
+        # rocprofv3 --stats) meaningless, so the default keeps one stream
+        self.wgrad_stream = os.environ.get("FDET_WGRAD_STREAM", "0") == "1"
         self._side = None
 
     def _t(self, kind: str, N: int, h: int, flops: float = 0.0, nbytes: float = 0.0):
