@@ -229,14 +229,35 @@ k_pw_wgrad_x3(const PwWgArgs a) {
   for (int r = 0; r < 16; ++r) w[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * ldw] = acc[r];
 }
 
+// dW[co][ci] = sum over the slabs, in a fixed order: 256 threads = 16 consecutive outputs x 16 slab lanes; lane g sums the
+// slabs g, g+16, ... (four independent partial sums: the loads of an output are in flight together instead of one
+// dependent chain of `nslab` loads per thread), then the 16 lanes are combined in lane order
 __global__ void __launch_bounds__(256)
 k_pw_wgrad_reduce(const float* __restrict__ ws, int nslab, int CoP32, int CiP32, int Cout, int Cin, float* __restrict__ dW) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= Cout * Cin) return;
-  const int co = t / Cin, ci = t - co * Cin;
+  __shared__ float part[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + o;
   float s = 0.f;
-  for (int b = 0; b < nslab; ++b) s += ws[((size_t)b * CoP32 + co) * CiP32 + ci];
-  dW[t] = s;
+  if (t < Cout * Cin) {
+    const int co = t / Cin, ci = t - co * Cin;
+    const float* __restrict__ p = ws + (size_t)co * CiP32 + ci;
+    const size_t st = (size_t)CoP32 * CiP32;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = g;
+    for (; b + 48 < nslab; b += 64) {
+      s0 += p[(size_t)b * st]; s1 += p[(size_t)(b + 16) * st]; s2 += p[(size_t)(b + 32) * st]; s3 += p[(size_t)(b + 48) * st];
+    }
+    for (; b < nslab; b += 16) s0 += p[(size_t)b * st];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  part[g][o] = s;
+  __syncthreads();
+  if (g == 0 && t < Cout * Cin) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r += part[k][o];
+    dW[t] = r;
+  }
 }
 
 // db[c] = sum_{n,p} dz[n][c][p] in two fixed-order stages: (channel, image slab) partial sums, then the slabs
@@ -354,7 +375,7 @@ extern "C" int fdet_pointwise_wgrad_bf16x3(const float* x, const float* dz, floa
   dim3 grid((unsigned)blocks, (unsigned)a.nslab);
   if (vec) hipLaunchKernelGGL(k_pw_wgrad_x3<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_pw_wgrad_x3<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3((Cout * Cin + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
+  hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3((Cout * Cin + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
                      a.nslab, a.CoT * 32, a.CiT * 32, Cout, Cin, dW);
   if (db) {
     float* bpart = (float*)ws + (size_t)a.nslab * a.CoT * 32 * a.CiT * 32;

@@ -252,25 +252,37 @@ k_stem_wgrad_k3(const float* __restrict__ x, const float* __restrict__ dy, float
   }
 }
 
-// dW[f][k] = sum_b ws[b][k][f] ; db[f] = sum_b wsb[b][f]   (fixed order)
+// dW[f][k] = sum_b ws[b][k][f] ; db[f] = sum_b wsb[b][f] in a fixed order: 256 threads = 16 consecutive outputs x 16 slab
+// lanes; lane g sums the slabs g, g+16, ... (four independent partial sums, so an output's loads are in flight together
+// instead of one dependent chain of `nblk` loads per thread), then the 16 lanes are combined in lane order
 __global__ void __launch_bounds__(256)
 k_stem_reduce(const float* __restrict__ ws, const float* __restrict__ wsb, int nblk, int KK, int F, int FP,
               float* __restrict__ dW, float* __restrict__ db) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < KK * FP) {
-    const int k = t / FP, f = t - k * FP;
-    if (f < F) {
-      float s = 0.f;
-      for (int b = 0; b < nblk; ++b) s += ws[((size_t)b * KK + k) * FP + f];
-      dW[(size_t)f * KK + k] = s;
+  __shared__ float part[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + o;
+  const bool isw = t < KK * FP, isb = !isw && t < KK * FP + FP;
+  const int f = isw ? t % FP : t - KK * FP;
+  float s = 0.f;
+  if ((isw || isb) && f < F) {
+    const float* __restrict__ p = isw ? ws + t : wsb + f;
+    const size_t st = isw ? (size_t)KK * FP : (size_t)FP;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = g;
+    for (; b + 48 < nblk; b += 64) {
+      s0 += p[(size_t)b * st]; s1 += p[(size_t)(b + 16) * st]; s2 += p[(size_t)(b + 32) * st]; s3 += p[(size_t)(b + 48) * st];
     }
-  } else if (t < KK * FP + FP) {
-    const int f = t - KK * FP;
-    if (f < F) {
-      float s = 0.f;
-      for (int b = 0; b < nblk; ++b) s += wsb[(size_t)b * FP + f];
-      db[f] = s;
-    }
+    for (; b < nblk; b += 16) s0 += p[(size_t)b * st];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  part[g][o] = s;
+  __syncthreads();
+  if (g == 0 && (isw || isb) && f < F) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r += part[k][o];
+    if (isw) dW[(size_t)f * KK + t / FP] = r;
+    else db[f] = r;
   }
 }
 
@@ -385,14 +397,14 @@ extern "C" int fdet_stem_wgrad(const float* x, const float* dy, float* dW, float
     const int nb = std::min(std::min(nitems, 4 * ncu), p.nblk);            // the workspace holds p.nblk slabs
     hipLaunchKernelGGL(k_stem_wgrad_k3, dim3(nb, p.FP / 64), dim3(512), 0, st, x, dy, wsW, wsb, N, F, p.FP, H, W, p.Ho, p.Wo, nseg);
     if (int rc = check_launch("fdet_stem_wgrad(k3)")) return rc;
-    hipLaunchKernelGGL(k_stem_reduce, dim3((p.KK * p.FP + p.FP + 255) / 256), dim3(256), 0, st, wsW, wsb, nb, p.KK, F, p.FP, dW, db);
+    hipLaunchKernelGGL(k_stem_reduce, dim3((p.KK * p.FP + p.FP + 15) / 16), dim3(256), 0, st, wsW, wsb, nb, p.KK, F, p.FP, dW, db);
     return check_launch("fdet_stem_wgrad(reduce)");
   } else {
     if (p.lds_wg > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_stem_wgrad<3, 2, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_wg);
     hipLaunchKernelGGL((k_stem_wgrad<3, 2, 1, 3>), grid, dim3(256), p.lds_wg, st, x, dy, wsW, wsb, N, F, p.FP, H, W, p.Ho, p.Wo, p.XS, p.DS);
   }
   if (int rc = check_launch("fdet_stem_wgrad")) return rc;
-  hipLaunchKernelGGL(k_stem_reduce, dim3((p.KK * p.FP + p.FP + 255) / 256), dim3(256), 0, st, wsW, wsb, p.nblk, p.KK, F,
+  hipLaunchKernelGGL(k_stem_reduce, dim3((p.KK * p.FP + p.FP + 15) / 16), dim3(256), 0, st, wsW, wsb, p.nblk, p.KK, F,
                      p.FP, dW, db);
   return check_launch("fdet_stem_wgrad(reduce)");
 }
