@@ -146,13 +146,21 @@ k_mb_dw(const DwArgs a) {
   // K*K*CW weights sit in LDS, and walks IMG images (blockIdx.y) with them; its threads: CGW = CW/8 channel groups
   // fastest, then strips of the image, so the pooled sums of one image's walk go to one row of `pool`
   constexpr int NC = (XS - 1) * S + K;                            // input columns a strip reads per row
-  extern __shared__ __attribute__((aligned(16))) float wl[];      // [K*K][CW] weights, then [CW] bias, then the pool scratch
+  // LDS: [K*K + 1][2][CGW][4] weights and (last row) bias, then the pool scratch.  A thread's 8 channels are two float4 in
+  // two planes (channels 0-3 / 4-7 of every group): the 16 lanes the LDS serves together read 16 CONSECUTIVE 16-byte
+  // chunks -- with the natural [tap][channel] order lanes cg and cg+8 are 256 B apart, on the same banks (PMC: 75 % of
+  // the LDS cycles were bank conflicts)
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  // the two-plane order pays for the 5x5 layers (0.150 -> 0.130 ms at 30x30x240); the 3x3 stride-2 layers measured SLOWER
+  // with it (0.157 -> 0.205 ms) and keep the natural order (plane offset 4 floats, group pitch 8)
+  constexpr bool PL = K == 5;
   const int C = a.C, CW = a.CW, CGW = CW >> 3, c0 = blockIdx.z * CW;
+  const int hoff = PL ? (CW >> 1) : 4, gp = PL ? 4 : 8;           // offset of channels 4-7, pitch of a channel group
   for (int t = threadIdx.x; t < K * K * (CW >> 2); t += 256) {
     const int tap = t / (CW >> 2), c4 = t - tap * (CW >> 2);
-    *reinterpret_cast<float4*>(wl + tap * CW + c4 * 4) = *reinterpret_cast<const float4*>(a.w + (size_t)tap * C + c0 + c4 * 4);
+    *reinterpret_cast<float4*>(wl + tap * CW + (c4 & 1) * hoff + (c4 >> 1) * gp) = *reinterpret_cast<const float4*>(a.w + (size_t)tap * C + c0 + c4 * 4);
   }
-  for (int t = threadIdx.x; t < CW; t += 256) wl[K * K * CW + t] = a.bias[c0 + t];
+  for (int t = threadIdx.x; t < CW; t += 256) wl[K * K * CW + ((t >> 2) & 1) * hoff + (t >> 3) * gp + (t & 3)] = a.bias[c0 + t];
   __syncthreads();
   const int per_wg = 256 / CGW;                                   // strips per workgroup pass (CGW <= 72 -> >= 3)
   const int cg = threadIdx.x % CGW, pl = threadIdx.x / CGW;
@@ -169,11 +177,13 @@ k_mb_dw(const DwArgs a) {
         // channel pairs ride in packed fp32 FMAs (v_pk_fma_f32): acc[q][h] = channels 2h, 2h+1 of output column q
         f32x2v acc[XS][4];
         {
-          const f32x2v* bp = reinterpret_cast<const f32x2v*>(wl + K * K * CW + cg * 8);
+          const float4 b0 = *reinterpret_cast<const float4*>(wl + K * K * CW + cg * gp);
+          const float4 b1 = *reinterpret_cast<const float4*>(wl + K * K * CW + hoff + cg * gp);
 #pragma unroll
-          for (int q = 0; q < XS; ++q)
-#pragma unroll
-            for (int h = 0; h < 4; ++h) acc[q][h] = bp[h];
+          for (int q = 0; q < XS; ++q) {
+            acc[q][0] = f32x2v{b0.x, b0.y}; acc[q][1] = f32x2v{b0.z, b0.w};
+            acc[q][2] = f32x2v{b1.x, b1.y}; acc[q][3] = f32x2v{b1.z, b1.w};
+          }
         }
 #pragma unroll 1                                                  // one row of taps at a time: ~120 VGPRs, 4 waves per SIMD hide the loads
         for (int ky = 0; ky < K; ++ky) {
@@ -186,10 +196,9 @@ k_mb_dw(const DwArgs a) {
             for (int h = 0; h < 4; ++h) xv[c][h] = f32x2v{bf2f(v[c][2 * h]), bf2f(v[c][2 * h + 1])};
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) {
-            const f32x2v* wt = reinterpret_cast<const f32x2v*>(wl + (ky * K + kx) * CW + cg * 8);
-            f32x2v wv[4];
-#pragma unroll
-            for (int h = 0; h < 4; ++h) wv[h] = wt[h];
+            const float4 w0 = *reinterpret_cast<const float4*>(wl + (ky * K + kx) * CW + cg * gp);
+            const float4 w1 = *reinterpret_cast<const float4*>(wl + (ky * K + kx) * CW + hoff + cg * gp);
+            const f32x2v wv[4] = {f32x2v{w0.x, w0.y}, f32x2v{w0.z, w0.w}, f32x2v{w1.x, w1.y}, f32x2v{w1.z, w1.w}};
 #pragma unroll
             for (int q = 0; q < XS; ++q)
 #pragma unroll
@@ -259,15 +268,17 @@ struct PwmArgs {
   int N, P, Cin, CiP, Cout, tiles_per_img, act;
 };
 
-template <int MT, bool WL, bool ST, int KU>
+template <int MT, bool WL, bool ST, int KU, int PT>
 __global__ void __launch_bounds__(256)
 k_mb_pw(const PwmArgs a) {
-  // WL: [MT*32][CiP + 8] weight panel (row stride = odd number of 16-byte units); ST: then 4 x [32][MT*32 + 8] output staging
+  // WL: [MT*32][CiP + 8] weight panel (row stride = odd number of 16-byte units); ST: then 4 x [32][MT*32 + 4] output staging.
+  // A wave owns PT x 32 positions (PT = 2 for narrow outputs: twice the operand bytes in flight per wave -- these layers
+  // are bound by memory latency x occupancy, PMC: waves parked 60-77 % of their cycles)
   extern __shared__ __attribute__((aligned(16))) u16 wpan[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int n = blockIdx.x / a.tiles_per_img;
-  const int p = (blockIdx.x - n * a.tiles_per_img) * 128 + wid * 32 + l31;      // this lane's position (B column)
+  const int pw0 = (blockIdx.x - n * a.tiles_per_img) * (128 * PT) + wid * (32 * PT);      // first position of this wave
   const int cob = blockIdx.y * (MT * 32);
   const int LS = a.CiP + 8;
   if (WL) {
@@ -278,24 +289,35 @@ k_mb_pw(const PwmArgs a) {
     }
     __syncthreads();
   }
-  const bool pok = p < a.P;
-  const u16* __restrict__ xr = a.x + ((size_t)n * a.P + (pok ? p : 0)) * a.Cin;
+  bool pok[PT];
+  const u16* __restrict__ xr[PT];
+#pragma unroll
+  for (int j = 0; j < PT; ++j) {
+    const int p = pw0 + 32 * j + l31;                             // this lane's position (B column) in sub-tile j
+    pok[j] = p < a.P;
+    xr[j] = a.x + ((size_t)n * a.P + (pok[j] ? p : 0)) * a.Cin;
+  }
   const float* __restrict__ gr = a.gate ? a.gate + (size_t)n * a.Cin : nullptr;
-  f32x16v acc[MT];
+  f32x16v acc[PT][MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int j = 0; j < PT; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][m][r] = 0.f;
   for (int k0 = 0; k0 < a.CiP; k0 += 16 * KU) {
     // KU k-steps of operand loads issued together (KU = 4 for Cin >= 128: one memory latency per 64 input channels)
-    u16x8 b[KU];
+    u16x8 b[PT][KU];
     float4 g0[KU], g1[KU];
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const int k = k0 + 16 * u + 8 * half;
       const bool kok = k < a.Cin;                                 // Cin % 8 == 0: a group of 8 is all in or all out
-      b[u] = *reinterpret_cast<const u16x8*>(xr + (kok ? k : 0));
-      if (!(pok && kok)) b[u] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < PT; ++j) {
+        b[j][u] = *reinterpret_cast<const u16x8*>(xr[j] + (kok ? k : 0));
+        if (!(pok[j] && kok)) b[j][u] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
       if (gr) {
         g0[u] = *reinterpret_cast<const float4*>(gr + (kok ? k : 0));
         g1[u] = *reinterpret_cast<const float4*>(gr + (kok ? k : 0) + 4);
@@ -305,95 +327,109 @@ k_mb_pw(const PwmArgs a) {
     for (int u = 0; u < KU; ++u) {
       if (KU > 1 && k0 + 16 * u >= a.CiP) break;                  // uniform
       const int k = k0 + 16 * u + 8 * half;
-      if (gr) {
-        const float gv[8] = {g0[u].x, g0[u].y, g0[u].z, g0[u].w, g1[u].x, g1[u].y, g1[u].z, g1[u].w};
+      bf16x8 bf[PT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[u][j] = f2bf(bf2f(b[u][j]) * gv[j]);
+      for (int j = 0; j < PT; ++j) {
+        if (gr) {
+          const float gv[8] = {g0[u].x, g0[u].y, g0[u].z, g0[u].w, g1[u].x, g1[u].y, g1[u].z, g1[u].w};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) b[j][u][i] = f2bf(bf2f(b[j][u][i]) * gv[i]);
+        }
+        bf[j] = __builtin_bit_cast(bf16x8, b[j][u]);
       }
-      const bf16x8 bf = __builtin_bit_cast(bf16x8, b[u]);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const bf16x8 af = WL ? *reinterpret_cast<const bf16x8*>(wpan + (m * 32 + l31) * LS + k)
                              : *reinterpret_cast<const bf16x8*>(a.w + (size_t)(cob + m * 32 + l31) * a.CiP + k);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[j][m], 0, 0, 0);
       }
     }
   }
-  // acc[m][r]: column = this lane's position, row (output channel) = cob + 32m + (r&3) + 8(r>>2) + 4half
-  const size_t row = ((size_t)n * a.P + (pok ? p : 0)) * a.Cout;
-  if (ST) {
-    // the wave's 32 positions x MT*32 channels go through LDS so that the stores walk memory contiguously (a position's
-    // channels are contiguous, and so are consecutive positions when the workgroup covers all of Cout)
-    constexpr int SS = MT * 32 + 8;
-    u16* stg = wpan + (WL ? MT * 32 * LS : 0) + wid * 32 * SS;
+  // acc[j][m][r]: column = this lane's position of sub-tile j, row (output channel) = cob + 32m + (r&3) + 8(r>>2) + 4half
+#pragma unroll
+  for (int j = 0; j < PT; ++j) {
+    const int p = pw0 + 32 * j + l31;
+    const size_t row = ((size_t)n * a.P + (pok[j] ? p : 0)) * a.Cout;
+    if (ST) {
+      // the wave's 32 positions x MT*32 channels go through LDS so that the stores walk memory contiguously (a position's
+      // channels are contiguous, and so are consecutive positions when the workgroup covers all of Cout).  Row pitch
+      // MT*32 + 4 bf16 = an odd number of 8-byte units: the 8-byte writes of 32 lanes fall on 64 distinct banks
+      constexpr int SS = MT * 32 + 4;
+      u16* stg = wpan + (WL ? MT * 32 * LS : 0) + wid * 32 * SS;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = cob + 32 * m + 8 * g + 4 * half;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = act_apply(acc[j][m][4 * g + i] + a.bias[ch + i], a.act);   // bias padded to CoP: always readable
+          if (a.res && pok[j] && ch < a.Cout) {
+            const u16x4 rv = *reinterpret_cast<const u16x4*>(a.res + row + ch);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += bf2f(rv[i]);
+          }
+          uint2 o;
+          o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(stg + l31 * SS + 32 * m + 8 * g + 4 * half) = o;
+        }
+      __syncthreads();
+      const int cw = min(MT * 32, a.Cout - cob), cpr = cw >> 3;   // 16-byte chunks per position
+      const int p0 = pw0 + 32 * j;
+      u16* __restrict__ yb = a.y + ((size_t)n * a.P + p0) * a.Cout + cob;
+      for (int idx = lane; idx < 32 * cpr; idx += 64) {
+        const int r = idx / cpr, c = idx - r * cpr;
+        if (p0 + r < a.P) {
+          const uint2 lo = *reinterpret_cast<const uint2*>(stg + r * SS + c * 8), hi = *reinterpret_cast<const uint2*>(stg + r * SS + c * 8 + 4);
+          *reinterpret_cast<uint4*>(yb + (size_t)r * a.Cout + c * 8) = uint4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+      if (j + 1 < PT) __syncthreads();                            // the staging rows are rewritten by the next sub-tile
+      continue;
+    }
+    // direct stores: the half-waves exchange 4-channel groups (v_permlane32_swap) so that the lower half owns channels
+    // 16q..16q+7 and the upper half 16q+8..16q+15 of the position: one 16-byte store each
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int ch = cob + 32 * m + 8 * g + 4 * half;
-        float v[4];
+      for (int q = 0; q < 2; ++q) {
+        const int co = cob + 32 * m + 16 * q + 8 * half;          // first of this lane's 8 channels after the exchange
+        unsigned pk[2][2];                                        // [group 2q, 2q+1][two packed bf16 pairs] before the exchange
+        float v[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = act_apply(acc[m][4 * g + i] + a.bias[ch + i], a.act);   // bias padded to CoP: always readable
-        if (a.res && pok && ch < a.Cout) {
-          const u16x4 rv = *reinterpret_cast<const u16x4*>(a.res + row + ch);
+        for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += bf2f(rv[i]);
-        }
-        uint2 o;
-        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-        *reinterpret_cast<uint2*>(stg + l31 * SS + 32 * m + 8 * g + 4 * half) = o;
-      }
-    __syncthreads();
-    const int cw = min(MT * 32, a.Cout - cob), cpr = cw >> 3;     // 16-byte chunks per position
-    const int p0 = (blockIdx.x - n * a.tiles_per_img) * 128 + wid * 32;
-    u16* __restrict__ yb = a.y + ((size_t)n * a.P + p0) * a.Cout + cob;
-    for (int idx = lane; idx < 32 * cpr; idx += 64) {
-      const int r = idx / cpr, c = idx - r * cpr;
-      if (p0 + r < a.P) *reinterpret_cast<uint4*>(yb + (size_t)r * a.Cout + c * 8) = *reinterpret_cast<const uint4*>(stg + r * SS + c * 8);
-    }
-    return;
-  }
-  // direct stores: the half-waves exchange 4-channel groups (v_permlane32_swap) so that the lower half owns channels
-  // 16q..16q+7 and the upper half 16q+8..16q+15 of the position: one 16-byte store each
+          for (int i = 0; i < 4; ++i) {
+            const int ch = cob + 32 * m + 8 * (2 * q + gq) + 4 * half + i;
+            v[gq][i] = act_apply(acc[j][m][4 * (2 * q + gq) + i] + a.bias[ch], a.act);
+          }
+        if (a.res) {
+          // the residual is added BEFORE the exchange, in this lane's own (pre-exchange) channel groups
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+          for (int gq = 0; gq < 2; ++gq) {
+            const int ch = cob + 32 * m + 8 * (2 * q + gq) + 4 * half;
+            if (pok[j] && ch < a.Cout) {
+              const u16x4 rv = *reinterpret_cast<const u16x4*>(a.res + row + ch);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int co = cob + 32 * m + 16 * q + 8 * half;            // first of this lane's 8 channels after the exchange
-      unsigned pk[2][2];                                          // [group 2q, 2q+1][two packed bf16 pairs] before the exchange
-      float v[2][4];
-#pragma unroll
-      for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int ch = cob + 32 * m + 8 * (2 * q + gq) + 4 * half + i;
-          v[gq][i] = act_apply(acc[m][4 * (2 * q + gq) + i] + a.bias[ch], a.act);
-        }
-      if (a.res) {
-        // the residual is added BEFORE the exchange, in this lane's own (pre-exchange) channel groups
-#pragma unroll
-        for (int gq = 0; gq < 2; ++gq) {
-          const int ch = cob + 32 * m + 8 * (2 * q + gq) + 4 * half;
-          if (pok && ch < a.Cout) {
-            const u16x4 rv = *reinterpret_cast<const u16x4*>(a.res + row + ch);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[gq][i] += bf2f(rv[i]);
+              for (int i = 0; i < 4; ++i) v[gq][i] += bf2f(rv[i]);
+            }
           }
         }
-      }
 #pragma unroll
-      for (int gq = 0; gq < 2; ++gq) {
-        pk[gq][0] = (unsigned)f2bf(v[gq][0]) | ((unsigned)f2bf(v[gq][1]) << 16);
-        pk[gq][1] = (unsigned)f2bf(v[gq][2]) | ((unsigned)f2bf(v[gq][3]) << 16);
+        for (int gq = 0; gq < 2; ++gq) {
+          pk[gq][0] = (unsigned)f2bf(v[gq][0]) | ((unsigned)f2bf(v[gq][1]) << 16);
+          pk[gq][1] = (unsigned)f2bf(v[gq][2]) | ((unsigned)f2bf(v[gq][3]) << 16);
+        }
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+        if (pok[j] && co < a.Cout) {                              // Cout % 8 == 0: 8 channels all in or all out
+          uint4 o; o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+          *reinterpret_cast<uint4*>(a.y + row + co) = o;
+        }
       }
-      const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
-      const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
-      if (pok && co < a.Cout) {                                   // Cout % 8 == 0: 8 channels all in or all out
-        uint4 o; o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
-        *reinterpret_cast<uint4*>(a.y + row + co) = o;
-      }
-    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ head
@@ -531,34 +567,44 @@ extern "C" int fdet_mb_se_gate(const float* pool, int HW, const float* w1, const
   return check_launch("fdet_mb_se_gate");
 }
 
-template <int MT, bool WL, bool ST, int KU>
-static int launch_pw3(const PwmArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+template <int MT, bool WL, bool ST, int KU, int PT>
+static int launch_pw4(PwmArgs a, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done && lds) {
-    FDET_REQUIRE(hipFuncSetAttribute((const void*)k_mb_pw<MT, WL, ST, KU>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess, "mb_pointwise: LDS");
+    FDET_REQUIRE(hipFuncSetAttribute((const void*)k_mb_pw<MT, WL, ST, KU, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess, "mb_pointwise: LDS");
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_mb_pw<MT, WL, ST, KU>), grid, dim3(256), lds, st, a);
+  a.tiles_per_img = (a.P + 128 * PT - 1) / (128 * PT);
+  FDET_REQUIRE((size_t)a.N * a.tiles_per_img < 0x7fffffffu, "mb_pointwise: too many position tiles");
+  dim3 grid((unsigned)((size_t)a.N * a.tiles_per_img), ((a.Cout + 31) / 32) / MT);
+  hipLaunchKernelGGL((k_mb_pw<MT, WL, ST, KU, PT>), grid, dim3(256), lds, st, a);
   return check_launch("fdet_mb_pointwise");
 }
 
 template <int MT, bool WL, bool ST>
-static int launch_pw2(const PwmArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  return a.CiP >= 128 ? launch_pw3<MT, WL, ST, 4>(a, grid, lds, st) : launch_pw3<MT, WL, ST, 1>(a, grid, lds, st);
+static int launch_pw2(const PwmArgs& a, size_t lds, hipStream_t st) {
+  // two 32-position sub-tiles per wave while the accumulators stay within ~100 registers (MT <= 3)
+  static const int pt_env = std::getenv("FDET_MB_PW_PT") ? std::atoi(std::getenv("FDET_MB_PW_PT")) : 0;
+  constexpr bool can2 = MT <= 3;
+  const bool pt2 = can2 && pt_env == 2;                           // measured slower (212 VGPRs: half the waves): opt-in only
+  if constexpr (can2) {
+    if (pt2) return a.CiP >= 128 ? launch_pw4<MT, WL, ST, 4, 2>(a, lds, st) : launch_pw4<MT, WL, ST, 1, 2>(a, lds, st);
+  }
+  return a.CiP >= 128 ? launch_pw4<MT, WL, ST, 4, 1>(a, lds, st) : launch_pw4<MT, WL, ST, 1, 1>(a, lds, st);
 }
 
 template <int MT>
-static int launch_pw(const PwmArgs& a, dim3 grid, hipStream_t st) {
+static int launch_pw(const PwmArgs& a, hipStream_t st) {
   // LDS budget 72 KB (2 workgroups per CU): the weight panel first (above 64 KB it stays in L2), then the output staging
   static const int no_stage = std::getenv("FDET_MB_PW_STAGE") ? !std::atoi(std::getenv("FDET_MB_PW_STAGE")) : 0;
   const size_t panel = (size_t)MT * 32 * (a.CiP + 8) * sizeof(u16);
-  const size_t stage = (size_t)4 * 32 * (MT * 32 + 8) * sizeof(u16);
+  const size_t stage = (size_t)4 * 32 * (MT * 32 + 4) * sizeof(u16);
   const bool wl = panel <= 64 * 1024;
   const bool stg = !no_stage && (wl ? panel : 0) + stage <= 72 * 1024;
-  if (wl && stg) return launch_pw2<MT, true, true>(a, grid, panel + stage, st);
-  if (wl) return launch_pw2<MT, true, false>(a, grid, panel, st);
-  if (stg) return launch_pw2<MT, false, true>(a, grid, stage, st);
-  return launch_pw2<MT, false, false>(a, grid, 0, st);
+  if (wl && stg) return launch_pw2<MT, true, true>(a, panel + stage, st);
+  if (wl) return launch_pw2<MT, true, false>(a, panel, st);
+  if (stg) return launch_pw2<MT, false, true>(a, stage, st);
+  return launch_pw2<MT, false, false>(a, 0, st);
 }
 
 extern "C" int fdet_mb_pointwise(const void* x, const void* w, const float* bias, const float* gate, const void* res, void* y,
@@ -568,21 +614,18 @@ extern "C" int fdet_mb_pointwise(const void* x, const void* w, const float* bias
   PwmArgs a;
   a.x = (const u16*)x; a.w = (const u16*)w; a.bias = bias; a.gate = gate; a.res = (const u16*)res; a.y = (u16*)y;
   a.N = N; a.P = P; a.Cin = Cin; a.CiP = (Cin + 15) / 16 * 16; a.Cout = Cout; a.act = act;
-  a.tiles_per_img = (P + 127) / 128;
   const int CoT = (Cout + 31) / 32;                               // 32-channel row tiles of the (zero padded) weight panel
   // one workgroup covers all output channels when it can (the input is then read once): up to 6 tiles = 192 channels (more costs occupancy: 9 tiles need 300 VGPRs)
   int MT = 1;
   for (int m : {6, 5, 4, 3, 2}) if (CoT % m == 0) { MT = m; break; }
-  FDET_REQUIRE((size_t)N * a.tiles_per_img < 0x7fffffffu, "mb_pointwise: too many position tiles");
-  dim3 grid((unsigned)((size_t)N * a.tiles_per_img), CoT / MT);
   hipStream_t st = (hipStream_t)stream;
   switch (MT) {
-    case 6: return launch_pw<6>(a, grid, st);
-    case 5: return launch_pw<5>(a, grid, st);
-    case 4: return launch_pw<4>(a, grid, st);
-    case 3: return launch_pw<3>(a, grid, st);
-    case 2: return launch_pw<2>(a, grid, st);
-    default: return launch_pw<1>(a, grid, st);
+    case 6: return launch_pw<6>(a, st);
+    case 5: return launch_pw<5>(a, st);
+    case 4: return launch_pw<4>(a, st);
+    case 3: return launch_pw<3>(a, st);
+    case 2: return launch_pw<2>(a, st);
+    default: return launch_pw<1>(a, st);
   }
 }
 
