@@ -54,7 +54,7 @@ __device__ __forceinline__ float4 load4(const unsigned char* p) {
 template <typename TIN>
 __global__ void __launch_bounds__(256)
 k_mb_stem(const TIN* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, u16* __restrict__ y,
-          int H, int W, int Ho, int Wo, float in_scale) {
+          int H, int W, int Ho, int Wo, float in_div) {
   constexpr int LW = 516;                                         // 2*256 + 1 input columns of a 256-column tile, padded
   __shared__ __attribute__((aligned(16))) float in[3][5][LW];
   const int n = blockIdx.z, oy0 = blockIdx.y * 2, ox0 = blockIdx.x * 256;
@@ -76,7 +76,7 @@ k_mb_stem(const TIN* __restrict__ x, const float* __restrict__ w, const float* _
       const int idx = threadIdx.x + 256 * j, r = idx / NV, c4 = idx - r * NV;
       if (idx < 15 * NV)
         *reinterpret_cast<float4*>(&in[0][0][0] + r * LW + 4 * c4) =
-            float4{val[j].x * in_scale, val[j].y * in_scale, val[j].z * in_scale, val[j].w * in_scale};
+            float4{val[j].x / in_div, val[j].y / in_div, val[j].z / in_div, val[j].w / in_div};      // IEEE division: uint8 frames give exactly the `x / 255.0` of the reference
     }
   } else {
     const int ncol = min(2 * (Wo - ox0) + 1, 513);
@@ -84,7 +84,7 @@ k_mb_stem(const TIN* __restrict__ x, const float* __restrict__ w, const float* _
       const int c = r / 5, iy = 2 * oy0 + (r - c * 5);
       const TIN* __restrict__ src = x + (((size_t)n * 3 + c) * H + (iy < H ? iy : 0)) * W + 2 * ox0;
       for (int t = threadIdx.x; t < ncol; t += 256)
-        in[c][r - c * 5][t] = (iy < H && 2 * ox0 + t < W) ? (float)src[t] * in_scale : 0.f;
+        in[c][r - c * 5][t] = (iy < H && 2 * ox0 + t < W) ? (float)src[t] / in_div : 0.f;
     }
   }
   __syncthreads();
@@ -510,7 +510,7 @@ extern "C" int fdet_mb_stem(const void* x, int x_is_u8, const float* w, const fl
   FDET_REQUIRE(N <= 65535 && H / 4 + 1 <= 65535, "mb_stem: batch or height beyond the launch grid");
   const int Ho = H / 2, Wo = W / 2;
   dim3 grid((Wo + 255) / 256, (Ho + 1) / 2, N);
-  if (x_is_u8) hipLaunchKernelGGL(k_mb_stem<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x, w, bias, (u16*)y, H, W, Ho, Wo, 1.0f / 255.0f);
+  if (x_is_u8) hipLaunchKernelGGL(k_mb_stem<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x, w, bias, (u16*)y, H, W, Ho, Wo, 255.0f);
   else hipLaunchKernelGGL(k_mb_stem<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, w, bias, (u16*)y, H, W, Ho, Wo, 1.0f);
   return check_launch("fdet_mb_stem");
 }

@@ -99,6 +99,14 @@ class MobilenetV3Backbone(BaseModel):
             self._mb_key = key
         return self._mb
 
+    def _stack_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(N,3,H,W) f32 in [0,1] or uint8 -> (N,5,S,S) sigmoid maps (what BaseModel.graphed_predict captures)."""
+        if self.training:
+            raise NotImplementedError("MobilenetV3Backbone: inference only (call .eval()); BatchNorm batch statistics and the "
+                                      "backward pass of this backbone are not built")
+        with torch.no_grad():
+            return self._packed_engine().forward(x)
+
     def forward(self, x: torch.Tensor, predict: torch.Tensor = torch.tensor(0)):
         if self.training:
             raise NotImplementedError("MobilenetV3Backbone: inference only (call .eval()); BatchNorm batch statistics and the "
@@ -110,8 +118,7 @@ class MobilenetV3Backbone(BaseModel):
                 x = self._preprocess(x)                  # uint8 at the model size goes straight to the stem (/255 fused there)
         elif x.dtype != torch.float32:
             raise TypeError(f"MobilenetV3Backbone.forward: expected float32 in [0,1], got {x.dtype}")
-        with torch.no_grad():
-            x = self._packed_engine().forward(x)
+        x = self._stack_forward(x)
         if predict == 1:
             x = self.single_non_max_suppression(x[0])
         return x

@@ -220,6 +220,20 @@ def test_predict_path_uint8_frames(golden):
     assert b2.dim() == 2 and b2.shape[1] == 5
 
 
+def test_graphed_predict_equals_eager(golden):
+    """The launch-bound demo path (preprocess -> ~45 backbone launches -> decode -> NMS) replayed from ONE HIP graph gives
+    the boxes of the eager path, frame after frame."""
+    net = _model(golden("g13_mobilenet_weights"))
+    net.reduce_bounding_boxes.probability_threshold = 0.3
+    g = torch.Generator().manual_seed(11)
+    frames = [torch.randint(0, 256, (2, 3, 480, 480), generator=g, dtype=torch.uint8).cuda() for _ in range(3)]
+    gp = net.graphed_predict(frames[0])
+    for f in frames:
+        want = net(f, torch.tensor(1))
+        got = gp.first(f)
+        assert torch.equal(got.cpu(), want.cpu())
+
+
 def test_training_mode_and_cpu_inputs_fail_loudly(golden):
     from fdet_amd import _native as N
     net = _model(golden("g13_mobilenet_weights"))
