@@ -136,6 +136,14 @@ int fdet_ssd_encode_targets(const float* boxes, const int32_t* box_offsets, int 
 size_t fdet_ssd_loss_ws_bytes(int B);
 int fdet_ssd_loss_fwd_bwd(const float* pred, const float* target, int B, int P, int neg_pos_ratio, float* loss,
                           float* grad, uint8_t* mask, void* ws, size_t ws_bytes, void* stream);
+/* The same loss split at its only batch-wide quantity, for data-parallel training (the positive count of
+ * losses/SSDLoss.py:86 is the count of the WHOLE batch): `parts` leaves the UNSCALED gradient of this rank's shard in
+ * grad and the shard's three fp64 sums [BCE, smooth-L1, positive priors] in sums; the caller SUM-all-reduces the three
+ * doubles; `finish` writes loss = (sums[1] + sums[0]) / sums[2] and scales grad by 1 / sums[2].  One rank: the pair
+ * equals fdet_ssd_loss_fwd_bwd.  ws of `finish`: >= 16 bytes. */
+int fdet_ssd_loss_parts(const float* pred, const float* target, int B, int P, int neg_pos_ratio, float* grad, uint8_t* mask,
+                        double* sums, void* ws, size_t ws_bytes, void* stream);
+int fdet_ssd_loss_finish(const double* sums, float* loss, float* grad, size_t n_grad, void* ws, size_t ws_bytes, void* stream);
 /* ReduceSSDBoundingBoxes.forward for a batch (datasets/utils.py:54-92): decode (with_priors: scale by
  * 1/ps and add the cell origin), threshold (strict >), xyxy, round half even, greedy NMS, xywh.
  *   x [B,P,5]; out [B,P,5] rows [score,x,y,w,h] (first out_counts[n] rows valid). */

@@ -600,6 +600,23 @@ k_ssd_loss_total(const double* __restrict__ part, int B, float* __restrict__ los
   }
 }
 
+// data-parallel form: the three batch sums (BCE, smooth-L1, positive priors) of THIS shard, fixed order, fp64
+__global__ void __launch_bounds__(64)
+k_ssd_loss_sums(const double* __restrict__ part, int B, double* __restrict__ sums) {
+  if (threadIdx.x == 0) {
+    double bce = 0.0, sl1 = 0.0, np = 0.0;
+    for (int n = 0; n < B; ++n) { bce += part[n * 3]; sl1 += part[n * 3 + 1]; np += part[n * 3 + 2]; }
+    sums[0] = bce; sums[1] = sl1; sums[2] = np;
+  }
+}
+__global__ void __launch_bounds__(64)
+k_ssd_loss_finish(const double* __restrict__ sums, float* __restrict__ loss, float* __restrict__ inv_npos) {
+  if (threadIdx.x == 0) {
+    loss[0] = (float)((sums[1] + sums[0]) / sums[2]);                  // :86 with the batch-wide sums
+    inv_npos[0] = (float)(1.0 / sums[2]);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_ssd_scale_grad(float* __restrict__ grad, size_t n, const float* __restrict__ inv_npos) {
   const float s = inv_npos[0];
@@ -709,6 +726,34 @@ extern "C" int fdet_ssd_loss_fwd_bwd(const float* pred, const float* target, int
     hipLaunchKernelGGL(k_ssd_scale_grad, dim3((unsigned)blocks), dim3(256), 0, st, grad, n, inv);
   }
   return check_launch("fdet_ssd_loss_fwd_bwd(total)");
+}
+
+extern "C" int fdet_ssd_loss_parts(const float* pred, const float* target, int B, int P, int neg_pos_ratio, float* grad,
+                                   uint8_t* mask, double* sums, void* ws, size_t ws_bytes, void* stream) {
+  FDET_REQUIRE(pred && target && sums && ws && B > 0 && P > 0 && neg_pos_ratio >= 0, "ssd_loss_parts: bad arguments");
+  FDET_REQUIRE((size_t)P * 4 <= 150 * 1024, "ssd_loss_parts: P=%d priors exceed the LDS tile", P);
+  if (ws_bytes < fdet_ssd_loss_ws_bytes(B)) return fail(FDET_EWORKSPACE, "ssd_loss_parts: workspace %zu < %zu bytes", ws_bytes, fdet_ssd_loss_ws_bytes(B));
+  double* part = (double*)ws;
+  const size_t lds = (size_t)P * 4;
+  if (int rc = set_lds(k_ssd_loss_image, lds)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_ssd_loss_image, dim3(B), dim3(256), lds, st, pred, target, P, neg_pos_ratio, grad, mask, part);
+  if (int rc = check_launch("fdet_ssd_loss_parts")) return rc;
+  hipLaunchKernelGGL(k_ssd_loss_sums, dim3(1), dim3(64), 0, st, part, B, sums);
+  return check_launch("fdet_ssd_loss_parts(sums)");
+}
+
+extern "C" int fdet_ssd_loss_finish(const double* sums, float* loss, float* grad, size_t n_grad, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  FDET_REQUIRE(sums && loss && ws && ws_bytes >= 16, "ssd_loss_finish: bad arguments (workspace of at least 16 bytes)");
+  float* inv = (float*)ws;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_ssd_loss_finish, dim3(1), dim3(64), 0, st, sums, loss, inv);
+  if (grad && n_grad) {
+    size_t blocks = (n_grad + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_ssd_scale_grad, dim3((unsigned)blocks), dim3(256), 0, st, grad, n_grad, inv);
+  }
+  return check_launch("fdet_ssd_loss_finish");
 }
 
 extern "C" int fdet_ssd_reduce_bounding_boxes(const float* x, int B, const int* h_patch_sizes, int nscales, int with_priors,

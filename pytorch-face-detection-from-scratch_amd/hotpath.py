@@ -180,6 +180,31 @@ def ssd_loss_fwd_bwd(pred: torch.Tensor, target: torch.Tensor, neg_pos_ratio: in
     return loss, grad, mask
 
 
+def ssd_loss_parts(pred: torch.Tensor, target: torch.Tensor, neg_pos_ratio: int = 10, want_grad: bool = True):
+    """Data-parallel half of ssd_loss: (sums (3,) f64 = [BCE, smooth-L1, positives] of THIS shard, UNSCALED grad or None)."""
+    pred, target = _f32(pred), _f32(target)
+    if pred.dim() != 3 or pred.shape[2] != 5 or pred.shape != target.shape:
+        raise ValueError(f"ssd_loss: expected matching (B,P,5) tensors, got {tuple(pred.shape)} / {tuple(target.shape)}")
+    B, P, _ = pred.shape
+    sums = torch.empty(3, dtype=torch.float64, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    ws = torch.empty(int(lib().fdet_ssd_loss_ws_bytes(B)) // 8 + 1, dtype=torch.float64, device=pred.device)
+    check(lib().fdet_ssd_loss_parts(ptr(pred), ptr(target), B, P, int(neg_pos_ratio), ptr(grad), None, ptr(sums, torch.float64),
+                                    ptr(ws, torch.float64), ws.numel() * 8, stream()), "fdet_ssd_loss_parts")
+    return sums, grad
+
+
+def ssd_loss_finish(sums: torch.Tensor, grad: Optional[torch.Tensor]) -> torch.Tensor:
+    """loss (1,) from the batch-wide sums (after the caller's SUM all-reduce); scales `grad` in place by 1 / positives."""
+    if sums.dtype != torch.float64 or sums.numel() != 3:
+        raise ValueError("ssd_loss_finish: sums must be the (3,) float64 tensor of ssd_loss_parts")
+    loss = torch.empty(1, dtype=F32, device=sums.device)
+    ws = torch.empty(4, dtype=F32, device=sums.device)
+    check(lib().fdet_ssd_loss_finish(ptr(sums, torch.float64), ptr(loss), ptr(grad), grad.numel() if grad is not None else 0,
+                                     ptr(ws), 16, stream()), "fdet_ssd_loss_finish")
+    return loss
+
+
 def ssd_reduce_bounding_boxes(x: torch.Tensor, prob_threshold: float, iou_threshold: float, img_w: float, img_h: float,
                               patch_sizes=SSD_PATCH_SIZES, with_priors: bool = True):
     """Batched ReduceSSDBoundingBoxes.forward: (B,P,5) -> (rows (B,P,5), counts (B,))."""

@@ -7,7 +7,9 @@ from pathlib import Path
 import torch
 
 from .. import hotpath as hp
-from ..dataparallel import rank_world
+import torch.distributed as dist
+
+from ..dataparallel import GradBucketReducer, rank_world, sync_parameters
 from ..losses.SSDLoss import ssd_loss
 from ..optim import SAMSGD
 
@@ -27,6 +29,7 @@ class ModelMetaSSD(_Base):
         self.automatic_optimization = True
         self.log_path = log_path
         self.opt = None
+        self._reducer = None
         self._logged = {}
 
     if not _HAVE_PL:
@@ -80,16 +83,29 @@ class ModelMetaSSD(_Base):
             raise RuntimeError("optimizer parameter order differs from the SSD stack's")
         P = {n: p.data for n, p in zip(names, params)}
         G = {n: sp.view(sp.grad, i) for i, n in enumerate(names)}
-        if rank_world()[1] > 1:
-            # ssd_loss divides by the positive count of the WHOLE batch (losses/SSDLoss.py:86): per-rank losses of
-            # disjoint shards do not add up to the loss of the concatenated batch, so a plain SUM all-reduce of the
-            # gradients would silently train a different objective.  Not built yet (needs the positive counts
-            # exchanged before the backward pass) -- fail loudly instead of diverging.
-            raise NotImplementedError("ModelMetaSSD.fused_train_step is single-process: data-parallel SSD training "
-                                      "needs a batch-wide positive count (losses/SSDLoss.py:86)")
+        world = rank_world()[1]
+        if world > 1 and self._reducer is None:
+            # one process per GPU: rank 0's parameters everywhere, then one SUM all-reduce of the flat gradient per step
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: data-parallel SSD training "
+                                   "needs a process group (bench.py / torch.distributed.run set one up)")
+            sync_parameters(sp.flat)
+            eng.mark_params_dirty()
+            self._reducer = GradBucketReducer(sp.grad, 0)
         masks = model._draw_masks(x.shape[0], x.device) if model.training else None
         y_hat, saved = eng.forward(x, P, masks, save=True)
-        loss, dy, _ = hp.ssd_loss_fwd_bwd(y_hat, y, 10, want_grad=True)
+        if world > 1:
+            # ssd_loss divides by the positive count of the WHOLE batch (losses/SSDLoss.py:86): the three batch sums are
+            # exchanged (24 bytes) BEFORE the gradient is scaled and back-propagated, so the N-rank step optimises
+            # exactly the single-process objective on the concatenated batch
+            sums, dy = hp.ssd_loss_parts(y_hat, y, 10, want_grad=True)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            loss = hp.ssd_loss_finish(sums, dy)
+        else:
+            loss, dy, _ = hp.ssd_loss_fwd_bwd(y_hat, y, 10, want_grad=True)
         eng.backward(saved, dy, P, G)
+        if world > 1:
+            self._reducer.launch_tail()
+            self._reducer.wait()
         self.opt.step(grads_in_flat=True)
         return loss, y_hat

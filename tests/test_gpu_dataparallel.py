@@ -20,7 +20,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run_ranks(tmp_path, F_, b_local, steps, live, world=2):
+def _run_ranks(tmp_path, F_, b_local, steps, live, world=2, kind="yolo"):
     out = str(tmp_path / "dp_rank0.pt")
     port = _free_port()
     procs = []
@@ -28,7 +28,7 @@ def _run_ranks(tmp_path, F_, b_local, steps, live, world=2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), out, str(F_),
-                                       str(b_local), str(steps), str(int(live))], env=env,
+                                       str(b_local), str(steps), str(int(live)), kind], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]
     for p, lg in zip(procs, logs):
@@ -59,3 +59,28 @@ def test_two_ranks_fused_train_step_equals_single_process(tmp_path, live_dropout
         assert float(d.max()) <= 2.1 * lr * steps, k
         frac_tight = float((d <= 1e-6 * max(1.0, float(p_ref.abs().max()))).float().mean())
         assert frac_tight >= 0.999, (k, frac_tight)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("live_dropout", [False, True], ids=["injected_masks", "per_rank_dropout_streams"])
+def test_two_ranks_ssd_fused_train_step_equals_single_process(tmp_path, live_dropout):
+    """SSD: `ssd_loss` divides by the positive count of the WHOLE batch (losses/SSDLoss.py:86).  Two ranks (one of them
+    holding an image without faces) exchange the three fp64 batch sums before the backward pass and the flat gradient
+    after it; loss, gradient and parameters equal the single-process step on the concatenated batch."""
+    import dp_worker
+    b_local, steps, world = 2, 2, 2
+    got = _run_ranks(tmp_path, 16, b_local, steps, live_dropout, world, kind="ssd")
+    params, grad, losses, enabled = dp_worker.run_rank_ssd(0, 1, world * b_local, steps, live_dropout, param_seed=0)
+    assert not enabled
+    for a, b in zip(got["loss_sum"], losses):
+        assert abs(a - b) <= 1e-5 * abs(b), (got["loss_sum"], losses)
+    gmax = float(grad.abs().max())
+    # the SECOND step's flat gradient: it is taken at parameters that may already differ in a few entries by Adam's
+    # sign-like first update (2 lr), and 2 + 2 images sum in another order than 4: within the north star's 1e-4
+    assert float((got["grad"] - grad).abs().max()) <= 1e-4 * gmax
+    lr = 1e-4
+    for k, p_ref in params.items():
+        d = (got["params"][k] - p_ref).abs()
+        assert float(d.max()) <= 2.1 * lr * steps, k
+        frac_tight = float((d <= 1e-6 * max(1.0, float(p_ref.abs().max()))).float().mean())
+        assert frac_tight >= 0.995, (k, frac_tight)

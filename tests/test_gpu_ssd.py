@@ -191,3 +191,30 @@ def test_ssd_config4_batch512_is_concatenation_of_its_halves():
         tot = (G_a[n] * n_a + G_b[n] * n_b) / n_all
         scale = max(1e-9, float(tot.abs().max()))
         assert float((G_all[n] - tot).abs().max()) <= 2e-4 * scale, n
+
+
+def test_ssd_loss_parts_of_two_shards_equal_the_whole_batch(hp):
+    """The data-parallel split of ssd_loss (fdet_ssd_loss_parts / fdet_ssd_loss_finish): the fp64 sums of two shards
+    added (what the 24-byte all-reduce does) and finished on each shard give the loss and the gradient of the
+    single-process call on the concatenated batch; one shard alone (no positives at all in the other) included."""
+    g = torch.Generator().manual_seed(31)
+    B = 6
+    pred = torch.rand(B, 4774, 5, generator=g) * 0.98 + 0.01
+    boxes = O.synthetic_boxes(B, SIZE, seed=32, max_faces=5)
+    boxes[4] = torch.zeros(0, 5); boxes[5] = torch.zeros(0, 5)            # shard B of the second split has no positives
+    tgt = hp.ssd_encode_targets(boxes, (SIZE, SIZE))
+    pred = pred.cuda()
+    loss_ref, grad_ref, _ = hp.ssd_loss_fwd_bwd(pred, tgt, 10, want_grad=True)
+    for cut in (3, 4):
+        sa, ga = hp.ssd_loss_parts(pred[:cut].contiguous(), tgt[:cut].contiguous(), 10)
+        sb, gb = hp.ssd_loss_parts(pred[cut:].contiguous(), tgt[cut:].contiguous(), 10)
+        if cut == 4:
+            assert float(sb[2]) == 0.0                                     # a rank without positives
+        tot = sa + sb
+        la = hp.ssd_loss_finish(tot, ga)
+        lb = hp.ssd_loss_finish(tot, gb)
+        assert float(la) == float(lb)
+        assert abs(float(la) - float(loss_ref)) <= 1e-6 * abs(float(loss_ref))
+        got = torch.cat([ga, gb])
+        assert bool(torch.isfinite(got).all())
+        assert torch.allclose(got, grad_ref, rtol=1e-6, atol=1e-9)
