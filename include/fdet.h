@@ -314,8 +314,9 @@ int fdet_pointwise_wgrad_bf16x3(const float* x, const float* dz, float* dW, floa
  *   fdet_mb_stem      x [N,3,H,W] f32 in [0,1] (x_is_u8: uint8, divided by 255) -> y [N,H/2,W/2,16]; Conv2dSame(3,16,3,s2)
  *                     with folded weights w [16][3][3][3] f32, bias [16], then Hardswish
  *   fdet_mb_depthwise KxK (3|5) depthwise, stride 1 (pad K/2) or 2 (TF "SAME"); w [K*K][C] f32, bias [C]; y [N,Ho,Wo,C];
- *                     pool [N][C] f32 (or NULL) receives the per-image channel sums of y (SqueezeExcite numerators)
- *   fdet_mb_se_gate   gate [N][C] = hardsigmoid(W2 relu(W1 (pool / HW) + b1) + b2); w1 [R][C], w2 [C][R] f32
+ *                     pool [N][slots][C] f32 (or NULL), slots = fdet_mb_depthwise_pool_slots(...): per-image partial channel
+ *                     sums of y, one row per workgroup column (SqueezeExcite numerators; no atomics: bit-reproducible)
+ *   fdet_mb_se_gate   gate [N][C] = hardsigmoid(W2 relu(W1 (sum of the pool rows / HW) + b1) + b2); w1 [R][C], w2 [C][R] f32
  *   fdet_mb_pointwise y [N,P,Cout] = act(W (x * gate) + bias) (+ res); x [N,P,Cin]; w bf16 [ceil32(Cout)][ceil16(Cin)] zero
  *                     padded; bias f32 [ceil32(Cout)]; gate [N][Cin] or NULL; res [N,P,Cout] or NULL
  *   fdet_mb_head      y [N,5,S,S] f32 = sigmoid(Conv2d(C,5,3,p1)(f)); f [N,S,S,C] bf16 (C % 16 == 0); w bf16 [2][64][C]: row
@@ -324,8 +325,9 @@ int fdet_pointwise_wgrad_bf16x3(const float* x, const float* dz, float* dW, floa
 int fdet_mb_stem(const void* x, int x_is_u8, const float* w, const float* bias, void* y, int N, int H, int W, void* stream);
 int fdet_mb_depthwise(const void* x, const float* w, const float* bias, void* y, float* pool, int N, int H, int W, int C,
                       int K, int stride, int act, void* stream);
-int fdet_mb_se_gate(const float* pool, int HW, const float* w1, const float* b1, const float* w2, const float* b2, int N,
-                    int C, int R, float* gate, void* stream);
+int fdet_mb_depthwise_pool_slots(int N, int H, int W, int C, int K, int stride);
+int fdet_mb_se_gate(const float* pool, int slots, int HW, const float* w1, const float* b1, const float* w2, const float* b2,
+                    int N, int C, int R, float* gate, void* stream);
 int fdet_mb_pointwise(const void* x, const void* w, const float* bias, const float* gate, const void* res, void* y, int N,
                       int P, int Cin, int Cout, int act, void* stream);
 size_t fdet_mb_head_ws_bytes(int N, int S);

@@ -80,7 +80,8 @@ SIGNATURES = {
     "fdet_pointwise_wgrad_bf16x3": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "fdet_mb_stem": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "fdet_mb_depthwise": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "fdet_mb_se_gate": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "fdet_mb_depthwise_pool_slots": (_I, [_I, _I, _I, _I, _I, _I]),
+    "fdet_mb_se_gate": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "fdet_mb_pointwise": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fdet_mb_head_ws_bytes": (_SZ, [_I, _I]),
     "fdet_mb_head": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P]),

@@ -123,6 +123,7 @@ struct DwArgs {
   const u16* x; const float* w; const float* bias; u16* y; float* pool;   // w: [K*K][C] folded; pool: [N][C] sums or null
   int N, H, W, C, Ho, Wo, pad, act, strips;                               // strips = ceil(Wo / XS) per output row
   int CW, IMG;                                                            // channels per workgroup (blockIdx.z chunk), images per workgroup
+  int pool_slots;                                                         // = gridDim.x: partial-sum rows per image in `pool`
 };
 
 // one input row of a strip: branch-free (always a valid address, zeros selected afterwards)
@@ -219,9 +220,10 @@ k_mb_dw(const DwArgs a) {
       }
     }
     if (a.pool) {
-      // SqueezeExcite numerators: fixed-order sum over this workgroup's threads per channel (LDS), then ONE float atomic
-      // per (workgroup, image, channel) -- the only order-dependent step (differences ~1 ulp of an fp32 mean that is
-      // then read through a hardsigmoid and a bf16 product)
+      // SqueezeExcite numerators: fixed-order sum over this workgroup's threads per channel (LDS), written to this
+      // workgroup's OWN row of `pool` ([image][gridDim.x][C]); k_mb_se adds the rows in order -- no atomics, so the forward
+      // is bit-reproducible (float atomics made run-to-run differences at the bf16-rounding level: a flipped rounding
+      // moved a sigmoid output by up to 1e-2)
 #pragma unroll
       for (int j = 0; j < 8; ++j) part[threadIdx.x * 8 + j] = (pl < per_wg) ? psum[j] : 0.f;
       __syncthreads();
@@ -229,7 +231,7 @@ k_mb_dw(const DwArgs a) {
         const int g = c >> 3, j = c & 7;
         float s = 0.f;
         for (int q = 0; q < per_wg; ++q) s += part[(q * CGW + g) * 8 + j];
-        atomicAdd(a.pool + (size_t)n * C + c0 + c, s);
+        a.pool[((size_t)n * a.pool_slots + blockIdx.x) * C + c0 + c] = s;
       }
       __syncthreads();                                            // `part` is rewritten for the next image
     }
@@ -238,11 +240,15 @@ k_mb_dw(const DwArgs a) {
 
 // ------------------------------------------------------------------------------------------------ SqueezeExcite gate
 __global__ void __launch_bounds__(256)
-k_mb_se(const float* __restrict__ pool, float inv_hw, const float* __restrict__ w1, const float* __restrict__ b1,
+k_mb_se(const float* __restrict__ pool, int slots, float inv_hw, const float* __restrict__ w1, const float* __restrict__ b1,
         const float* __restrict__ w2, const float* __restrict__ b2, int C, int R, float* __restrict__ gate) {
   __shared__ float m[576], h[160];
   const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) m[c] = pool[(size_t)n * C + c] * inv_hw;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int q = 0; q < slots; ++q) s += pool[((size_t)n * slots + q) * C + c];      // the depthwise workgroups' partial sums, in order
+    m[c] = s * inv_hw;
+  }
   __syncthreads();
   for (int r = threadIdx.x; r < R; r += 256) {
     float s = b1[r];
@@ -515,21 +521,31 @@ extern "C" int fdet_mb_stem(const void* x, int x_is_u8, const float* w, const fl
   return check_launch("fdet_mb_stem");
 }
 
+// launch geometry of the depthwise kernel (also what sizes the SqueezeExcite partial-sum rows)
+struct DwPlan { int strips, nchunk, CW, bx, IMG; };
+static DwPlan dw_plan(int N, int C, int Ho, int Wo, int XS) {
+  DwPlan p;
+  p.strips = (Wo + XS - 1) / XS;
+  // channel chunks of at most 192 (28 KB of LDS with 5x5 taps: 5 workgroups per CU); the chunk must be a multiple of 8
+  p.nchunk = (C + 191) / 192;
+  while (p.nchunk < C / 8 && C % (8 * p.nchunk)) ++p.nchunk;
+  p.CW = C / p.nchunk;
+  const int CGW = p.CW / 8, per_wg = 256 / CGW;
+  const int passes = (Ho * p.strips + per_wg - 1) / per_wg;       // workgroup passes over one image's strips
+  // workgroup columns per image: a function of the IMAGE geometry only (at most 16), so that the order in which an
+  // image's SqueezeExcite sums are added does not depend on the batch size; beyond ~8192 workgroups per launch a
+  // workgroup takes several images with one fill of its weights
+  p.bx = std::min(passes, 16);
+  const long long total = (long long)N * p.nchunk * p.bx;
+  p.IMG = (int)std::min<long long>(std::max<long long>(1, total / 8192), 64);
+  return p;
+}
+static int dw_xs(int K, int stride) { return stride == 1 ? 4 : 2; }
+
 template <int K, int S, int XS>
 static int launch_dw(DwArgs a, hipStream_t st) {
-  a.strips = (a.Wo + XS - 1) / XS;
-  // channel chunks of at most 192 (28 KB of LDS with 5x5 taps: 5 workgroups per CU); the chunk must be a multiple of 8
-  int nchunk = (a.C + 191) / 192;
-  while (nchunk < a.C / 8 && a.C % (8 * nchunk)) ++nchunk;
-  a.CW = a.C / nchunk;
-  const int CGW = a.CW / 8, per_wg = 256 / CGW;
-  const int passes = (a.Ho * a.strips + per_wg - 1) / per_wg;     // workgroup passes over one image's strips
-  // ~4096 workgroups for the whole launch; beyond that a workgroup takes several passes, then several images, with one
-  // fill of its weights
-  const long long total = (long long)a.N * nchunk * passes;
-  const int ppw = (int)std::max(1LL, total / 4096);
-  const int bx = (passes + std::min(ppw, passes) - 1) / std::min(ppw, passes);
-  a.IMG = std::min(std::max(1, ppw / passes), 64);
+  const DwPlan p = dw_plan(a.N, a.C, a.Ho, a.Wo, XS);
+  a.strips = p.strips; a.CW = p.CW; a.IMG = p.IMG; a.pool_slots = p.bx;
   const size_t lds = ((size_t)K * K * a.CW + a.CW + 256 * 8) * sizeof(float);
   static bool attr_done = false;                                  // per instantiation
   if (!attr_done) {
@@ -537,8 +553,13 @@ static int launch_dw(DwArgs a, hipStream_t st) {
     attr_done = true;
   }
   FDET_REQUIRE(lds <= 80 * 1024, "mb_depthwise: channel chunk does not fit LDS");
-  hipLaunchKernelGGL((k_mb_dw<K, S, XS>), dim3(bx, (a.N + a.IMG - 1) / a.IMG, nchunk), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_mb_dw<K, S, XS>), dim3(p.bx, (a.N + a.IMG - 1) / a.IMG, p.nchunk), dim3(256), lds, st, a);
   return check_launch("fdet_mb_depthwise");
+}
+
+extern "C" int fdet_mb_depthwise_pool_slots(int N, int H, int W, int C, int K, int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (K != 3 && K != 5) || (stride != 1 && stride != 2)) return 0;
+  return dw_plan(N, C, (H + stride - 1) / stride, (W + stride - 1) / stride, dw_xs(K, stride)).bx;
 }
 
 extern "C" int fdet_mb_depthwise(const void* x, const float* w, const float* bias, void* y, float* pool, int N, int H, int W,
@@ -552,7 +573,6 @@ extern "C" int fdet_mb_depthwise(const void* x, const float* w, const float* bia
   // stride 1: symmetric K/2.  stride 2: TF "SAME": total = max((Ho-1)*2 + K - H, 0), the smaller half in front
   a.pad = stride == 1 ? K / 2 : std::max((a.Ho - 1) * 2 + K - H, 0) / 2;
   if (stride == 2) FDET_REQUIRE(H == W, "mb_depthwise: stride-2 layers need square maps (one pad value for both axes)");
-  if (pool) (void)hipMemsetAsync(pool, 0, (size_t)N * C * sizeof(float), (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   if (K == 3 && stride == 1) return launch_dw<3, 1, 4>(a, st);
   if (K == 3) return launch_dw<3, 2, 2>(a, st);
@@ -560,10 +580,10 @@ extern "C" int fdet_mb_depthwise(const void* x, const float* w, const float* bia
   return launch_dw<5, 2, 2>(a, st);
 }
 
-extern "C" int fdet_mb_se_gate(const float* pool, int HW, const float* w1, const float* b1, const float* w2, const float* b2,
-                               int N, int C, int R, float* gate, void* stream) {
-  FDET_REQUIRE(pool && w1 && b1 && w2 && b2 && gate && N > 0 && C > 0 && C <= 576 && R > 0 && R <= 160 && HW > 0, "mb_se_gate: bad arguments");
-  hipLaunchKernelGGL(k_mb_se, dim3(N), dim3(256), 0, (hipStream_t)stream, pool, 1.0f / (float)HW, w1, b1, w2, b2, C, R, gate);
+extern "C" int fdet_mb_se_gate(const float* pool, int slots, int HW, const float* w1, const float* b1, const float* w2,
+                               const float* b2, int N, int C, int R, float* gate, void* stream) {
+  FDET_REQUIRE(pool && w1 && b1 && w2 && b2 && gate && N > 0 && C > 0 && C <= 576 && R > 0 && R <= 160 && HW > 0 && slots > 0, "mb_se_gate: bad arguments");
+  hipLaunchKernelGGL(k_mb_se, dim3(N), dim3(256), 0, (hipStream_t)stream, pool, slots, 1.0f / (float)HW, w1, b1, w2, b2, C, R, gate);
   return check_launch("fdet_mb_se_gate");
 }
 
@@ -615,14 +635,16 @@ extern "C" int fdet_mb_pointwise(const void* x, const void* w, const float* bias
   a.x = (const u16*)x; a.w = (const u16*)w; a.bias = bias; a.gate = gate; a.res = (const u16*)res; a.y = (u16*)y;
   a.N = N; a.P = P; a.Cin = Cin; a.CiP = (Cin + 15) / 16 * 16; a.Cout = Cout; a.act = act;
   const int CoT = (Cout + 31) / 32;                               // 32-channel row tiles of the (zero padded) weight panel
-  // one workgroup covers all output channels when it can (the input is then read once): up to 6 tiles = 192 channels (more costs occupancy: 9 tiles need 300 VGPRs)
-  int MT = 1;
-  for (int m : {6, 5, 4, 3, 2}) if (CoT % m == 0) { MT = m; break; }
+  // Row tiles per workgroup (the rest of Cout goes to blockIdx.y, re-reading the input from L2).  Measured over this
+  // network's layers: 2 tiles (a position's 64 channels = one 128-byte line per workgroup) beat 4-6 tiles by 20-33 % on
+  // the wide outputs (240, 576 channels: more waves in flight per CU matter more than reading the input once), 3 tiles
+  // when the count is a multiple of 3 but odd (72, 88, 96, 288 channels), and single tiles for the rest -- never for
+  // output-dominated layers with an even count: 64-byte pieces of a position written by different workgroups cost 2.3x
+  static const int mt_force = std::getenv("FDET_MB_PW_MT") ? std::atoi(std::getenv("FDET_MB_PW_MT")) : 0;
+  int MT = CoT % 2 == 0 ? 2 : (CoT % 3 == 0 ? 3 : 1);
+  if (mt_force >= 1 && mt_force <= 3 && CoT % mt_force == 0) MT = mt_force;
   hipStream_t st = (hipStream_t)stream;
   switch (MT) {
-    case 6: return launch_pw<6>(a, st);
-    case 5: return launch_pw<5>(a, st);
-    case 4: return launch_pw<4>(a, st);
     case 3: return launch_pw<3>(a, st);
     case 2: return launch_pw<2>(a, st);
     default: return launch_pw<1>(a, st);

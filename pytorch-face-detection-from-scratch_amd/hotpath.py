@@ -696,27 +696,35 @@ def mb_stem(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tenso
 
 
 def mb_depthwise(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, K: int, stride: int, act: int, want_pool: bool):
-    """x (N,H,W,C) bf16 -> (y (N,Ho,Wo,C) bf16, per-image channel sums (N,C) f32 or None); w (K*K,C) f32."""
+    """x (N,H,W,C) bf16 -> (y (N,Ho,Wo,C) bf16, per-image partial channel sums (N,slots,C) f32 or None); w (K*K,C) f32."""
     if x.dim() != 4 or x.dtype != BF16:
         raise ValueError("mb_depthwise: expected (N,H,W,C) bf16")
     Nn, H, W, C = x.shape
     _chk4(w, (K * K, C), "depthwise weight"); _chk4(bias, (C,), "depthwise bias")
     Ho, Wo = -(-H // stride), -(-W // stride)
     y = torch.empty(Nn, Ho, Wo, C, dtype=BF16, device=x.device)
-    pool = torch.empty(Nn, C, dtype=F32, device=x.device) if want_pool else None
+    pool = None
+    if want_pool:
+        slots = int(lib().fdet_mb_depthwise_pool_slots(Nn, H, W, C, K, stride))
+        if slots <= 0:
+            raise ValueError("mb_depthwise: unsupported shape")
+        pool = torch.empty(Nn, slots, C, dtype=F32, device=x.device)
     check(lib().fdet_mb_depthwise(ptr(x, BF16), ptr(w), ptr(bias), ptr(y, BF16), ptr(pool), Nn, H, W, C, K, stride, act, stream()),
           "fdet_mb_depthwise")
     return y, pool
 
 
 def mb_se_gate(pool: torch.Tensor, HW: int, w1, b1, w2, b2) -> torch.Tensor:
-    """gate (N,C) = hardsigmoid(W2 relu(W1 pool/HW + b1) + b2); w1 (R,C), w2 (C,R)."""
-    Nn, C = pool.shape
+    """gate (N,C) = hardsigmoid(W2 relu(W1 mean + b1) + b2), mean = sum of the pool rows / HW; pool (N,slots,C) as
+    mb_depthwise returns it (or (N,C)); w1 (R,C), w2 (C,R)."""
+    if pool.dim() == 2:
+        pool = pool.unsqueeze(1)
+    Nn, slots, C = pool.shape
     R = w1.shape[0]
     _chk4(w1, (R, C), "se reduce weight"); _chk4(b1, (R,), "se reduce bias")
     _chk4(w2, (C, R), "se expand weight"); _chk4(b2, (C,), "se expand bias")
     gate = torch.empty(Nn, C, dtype=F32, device=pool.device)
-    check(lib().fdet_mb_se_gate(ptr(pool), HW, ptr(w1), ptr(b1), ptr(w2), ptr(b2), Nn, C, R, ptr(gate), stream()), "fdet_mb_se_gate")
+    check(lib().fdet_mb_se_gate(ptr(pool), slots, HW, ptr(w1), ptr(b1), ptr(w2), ptr(b2), Nn, C, R, ptr(gate), stream()), "fdet_mb_se_gate")
     return gate
 
 
