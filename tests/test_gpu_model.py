@@ -561,3 +561,31 @@ def test_torchscript_export_matches_eager(fd, golden, tmp_path):
     assert torch.ops.fdet.nms(boxes, scores, 0.5).tolist() == [0, 2]
     if hasattr(torch.ops, "torchvision") and hasattr(torch.ops.torchvision, "nms"):
         assert torch.ops.torchvision.nms(boxes, scores, 0.5).tolist() == [0, 2]
+
+
+def test_fused_train_step_is_bit_reproducible(fd):
+    """Every reduction of the step (weight-gradient slabs, loss sum, head partials) runs in a fixed order and nothing
+    uses float atomics: two models started from the same parameters and fed the same batches and dropout masks hold
+    bit-identical parameters, gradients and losses after three steps (F=64: the benchmarked bf16x3 kernels)."""
+    from fdet_amd.models import ModelMeta
+    F, size, S, nb, B = 64, 480, 10, 10, 4
+    spec = O.poolresnet_spec(F, (3, size, size), S, nb)
+    P = O.init_params(spec, seed=5)
+    runs = []
+    for _ in range(2):
+        model = _load(_build(fd, "poolresnet", F, size, S, nb), P)
+        mm = ModelMeta(model=model, lr=1e-4)
+        mm.configure_optimizers()
+        model.train()
+        g = torch.Generator().manual_seed(17)
+        losses = []
+        for step in range(1, 4):
+            x = torch.rand(B, 3, size, size, generator=g).cuda()
+            y = torch.stack([O.encode_targets(b, (size, size), S) for b in O.synthetic_boxes(B, size, seed=step)]).cuda()
+            model.set_dropout_masks(O.make_dropout_masks(spec, B, seed=200 + step))
+            lsum, y_hat, _ = mm.fused_train_step(x, y)
+            losses.append(float(lsum))
+        runs.append((losses, mm.opt.space.flat.clone(), mm.opt.space.grad.clone(), y_hat.clone()))
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1:], runs[1][1:]):
+        assert torch.equal(a, b)
