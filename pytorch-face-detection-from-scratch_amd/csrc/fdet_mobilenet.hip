@@ -532,10 +532,11 @@ static DwPlan dw_plan(int N, int C, int Ho, int Wo, int XS) {
   p.CW = C / p.nchunk;
   const int CGW = p.CW / 8, per_wg = 256 / CGW;
   const int passes = (Ho * p.strips + per_wg - 1) / per_wg;       // workgroup passes over one image's strips
-  // workgroup columns per image: a function of the IMAGE geometry only (at most 16), so that the order in which an
+  // workgroup columns per image: a function of the IMAGE geometry only (about 16), so that the order in which an
   // image's SqueezeExcite sums are added does not depend on the batch size; beyond ~8192 workgroups per launch a
   // workgroup takes several images with one fill of its weights
-  p.bx = std::min(passes, 16);
+  const int ppi = std::max(1, (passes + 8) / 16);                 // passes per workgroup: ~16 columns, evenly loaded
+  p.bx = (passes + ppi - 1) / ppi;
   const long long total = (long long)N * p.nchunk * p.bx;
   p.IMG = (int)std::min<long long>(std::max<long long>(1, total / 8192), 64);
   return p;
