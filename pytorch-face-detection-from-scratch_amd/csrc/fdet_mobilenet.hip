@@ -43,6 +43,38 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
+template <int ACT> __device__ __forceinline__ float act_c(float v) {
+  if (ACT == 1) return v > 0.f ? v : 0.f;
+  if (ACT == 2) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+  return v;
+}
+// bias + activation applied to a whole accumulator set with the activation a compile-time constant: a run-time `act` inside
+// the element loops cost two scalar compares and branches PER ELEMENT (the pointwise kernels were instruction-issue
+// bound: 4 waves per SIMD each active 24 % of their cycles)
+template <int ACT, int PT, int MT>
+__device__ __forceinline__ void pw_bias_act(f32x16v (&acc)[PT][MT], const float* __restrict__ bias_cob, int half) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b = *reinterpret_cast<const float4*>(bias_cob + 32 * m + 8 * g + 4 * half);   // bias padded to CoP: always readable
+#pragma unroll
+      for (int j = 0; j < PT; ++j) {
+        acc[j][m][4 * g + 0] = act_c<ACT>(acc[j][m][4 * g + 0] + b.x);
+        acc[j][m][4 * g + 1] = act_c<ACT>(acc[j][m][4 * g + 1] + b.y);
+        acc[j][m][4 * g + 2] = act_c<ACT>(acc[j][m][4 * g + 2] + b.z);
+        acc[j][m][4 * g + 3] = act_c<ACT>(acc[j][m][4 * g + 3] + b.w);
+      }
+    }
+}
+template <int ACT, int XS>
+__device__ __forceinline__ void dw_act(f32x2v (&acc)[XS][4]) {
+#pragma unroll
+  for (int q = 0; q < XS; ++q)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { acc[q][h].x = act_c<ACT>(acc[q][h].x); acc[q][h].y = act_c<ACT>(acc[q][h].y); }
+}
+
 // ------------------------------------------------------------------------------------------------ stem
 __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 load4(const unsigned char* p) {
@@ -206,13 +238,14 @@ k_mb_dw(const DwArgs a) {
               for (int h = 0; h < 4; ++h) acc[q][h] = __builtin_elementwise_fma(xv[q * S + kx][h], wv[h], acc[q][h]);
           }
         }
+        if (a.act == 2) dw_act<2, XS>(acc); else if (a.act == 1) dw_act<1, XS>(acc);
 #pragma unroll
         for (int q = 0; q < XS; ++q) {
           if (ox0 + q >= a.Wo) break;
           u16x8 o;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            o[j] = f2bf(act_apply(acc[q][j >> 1][j & 1], a.act));
+            o[j] = f2bf(acc[q][j >> 1][j & 1]);
             psum[j] += bf2f(o[j]);                                // the pool sees what the next layer reads
           }
           *reinterpret_cast<u16x8*>(a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox0 + q) * C + c0 + cg * 8) = o;
@@ -353,6 +386,9 @@ k_mb_pw(const PwmArgs a) {
     }
   }
   // acc[j][m][r]: column = this lane's position of sub-tile j, row (output channel) = cob + 32m + (r&3) + 8(r>>2) + 4half
+  if (a.act == 2) pw_bias_act<2, PT, MT>(acc, a.bias + cob, half);
+  else if (a.act == 1) pw_bias_act<1, PT, MT>(acc, a.bias + cob, half);
+  else pw_bias_act<0, PT, MT>(acc, a.bias + cob, half);
 #pragma unroll
   for (int j = 0; j < PT; ++j) {
     const int p = pw0 + 32 * j + l31;
@@ -370,7 +406,7 @@ k_mb_pw(const PwmArgs a) {
           const int ch = cob + 32 * m + 8 * g + 4 * half;
           float v[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = act_apply(acc[j][m][4 * g + i] + a.bias[ch + i], a.act);   // bias padded to CoP: always readable
+          for (int i = 0; i < 4; ++i) v[i] = acc[j][m][4 * g + i];
           if (a.res && pok[j] && ch < a.Cout) {
             const u16x4 rv = *reinterpret_cast<const u16x4*>(a.res + row + ch);
 #pragma unroll
@@ -407,10 +443,7 @@ k_mb_pw(const PwmArgs a) {
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int ch = cob + 32 * m + 8 * (2 * q + gq) + 4 * half + i;
-            v[gq][i] = act_apply(acc[j][m][4 * (2 * q + gq) + i] + a.bias[ch], a.act);
-          }
+          for (int i = 0; i < 4; ++i) v[gq][i] = acc[j][m][4 * (2 * q + gq) + i];
         if (a.res) {
           // the residual is added BEFORE the exchange, in this lane's own (pre-exchange) channel groups
 #pragma unroll
