@@ -305,6 +305,7 @@ struct PwmArgs {
   const u16* res;      // [N][P][Cout] or null
   u16* y;              // [N][P][Cout]
   int N, P, Cin, CiP, Cout, tiles_per_img, act;
+  unsigned cpr_magic;  // ceil(2^32 / (CiP / 8)): t / (CiP/8) = umulhi(t, magic) for the panel's piece indices
 };
 
 template <int MT, bool WL, bool ST, int KU, int PT>
@@ -321,10 +322,22 @@ k_mb_pw(const PwmArgs a) {
   const int cob = blockIdx.y * (MT * 32);
   const int LS = a.CiP + 8;
   if (WL) {
-    const int cpr = a.CiP >> 3;                                   // 16-byte chunks per weight row
-    for (int t = threadIdx.x; t < MT * 32 * cpr; t += 256) {
-      const int r = t / cpr, c = t - r * cpr;
-      *reinterpret_cast<u16x8*>(wpan + r * LS + c * 8) = *reinterpret_cast<const u16x8*>(a.w + (size_t)(cob + r) * a.CiP + c * 8);
+    // the weight panel: four 16-byte pieces per thread in flight at a time (a load -> wait -> LDS write loop serialised
+    // one L2 round trip per piece: up to 27 per thread for the 288-channel panels)
+    const int cpr = a.CiP >> 3, total = MT * 32 * cpr;            // 16-byte chunks per weight row
+    for (int t0 = threadIdx.x; t0 < total; t0 += 1024) {
+      u16x8 v[4];
+      int dst[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = min(t0 + 256 * u, total - 1);
+        const int r = (int)__umulhi((unsigned)t, a.cpr_magic), c = t - r * cpr;
+        v[u] = *reinterpret_cast<const u16x8*>(a.w + (size_t)(cob + r) * a.CiP + c * 8);
+        dst[u] = r * LS + c * 8;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (t0 + 256 * u < total) *reinterpret_cast<u16x8*>(wpan + dst[u]) = v[u];
     }
     __syncthreads();
   }
@@ -668,6 +681,7 @@ extern "C" int fdet_mb_pointwise(const void* x, const void* w, const float* bias
   PwmArgs a;
   a.x = (const u16*)x; a.w = (const u16*)w; a.bias = bias; a.gate = gate; a.res = (const u16*)res; a.y = (u16*)y;
   a.N = N; a.P = P; a.Cin = Cin; a.CiP = (Cin + 15) / 16 * 16; a.Cout = Cout; a.act = act;
+  a.cpr_magic = (unsigned)(0xFFFFFFFFull / (unsigned)(a.CiP / 8)) + 1u;
   const int CoT = (Cout + 31) / 32;                               // 32-channel row tiles of the (zero padded) weight panel
   // Row tiles per workgroup (the rest of Cout goes to blockIdx.y, re-reading the input from L2).  Measured over this
   // network's layers: 2 tiles (a position's 64 channels = one 128-byte line per workgroup) beat 4-6 tiles by 20-33 % on
