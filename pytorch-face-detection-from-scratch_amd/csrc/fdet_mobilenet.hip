@@ -351,12 +351,7 @@ k_mb_pw(const PwmArgs a) {
   }
   const float* __restrict__ gr = a.gate ? a.gate + (size_t)n * a.Cin : nullptr;
   f32x16v acc[PT][MT];
-#pragma unroll
-  for (int j = 0; j < PT; ++j)
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][m][r] = 0.f;
+  const f32x16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < a.CiP; k0 += 16 * KU) {
     // KU k-steps of operand loads issued together (KU = 4 for Cin >= 128: one memory latency per 64 input channels)
     u16x8 b[PT][KU];
@@ -393,8 +388,11 @@ k_mb_pw(const PwmArgs a) {
       for (int m = 0; m < MT; ++m) {
         const bf16x8 af = WL ? *reinterpret_cast<const bf16x8*>(wpan + (m * 32 + l31) * LS + k)
                              : *reinterpret_cast<const bf16x8*>(a.w + (size_t)(cob + m * 32 + l31) * a.CiP + k);
+        // the very first k-step takes a constant-zero C operand: no accumulator initialisation instructions
 #pragma unroll
-        for (int j = 0; j < PT; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[j][m], 0, 0, 0);
+        for (int j = 0; j < PT; ++j)
+          acc[j][m] = (k0 == 0 && u == 0) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], zero16, 0, 0, 0)
+                                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[j][m], 0, 0, 0);
       }
     }
   }
@@ -434,8 +432,9 @@ k_mb_pw(const PwmArgs a) {
       const int cw = min(MT * 32, a.Cout - cob), cpr = cw >> 3;   // 16-byte chunks per position
       const int p0 = pw0 + 32 * j;
       u16* __restrict__ yb = a.y + ((size_t)n * a.P + p0) * a.Cout + cob;
+      const unsigned om = 0xFFFFFFFFu / (unsigned)cpr + 1u;       // idx / cpr = umulhi(idx, om) for idx < 32 * cpr (wave-uniform: scalar)
       for (int idx = lane; idx < 32 * cpr; idx += 64) {
-        const int r = idx / cpr, c = idx - r * cpr;
+        const int r = (int)__umulhi((unsigned)idx, om), c = idx - r * cpr;
         if (p0 + r < a.P) {
           const uint2 lo = *reinterpret_cast<const uint2*>(stg + r * SS + c * 8), hi = *reinterpret_cast<const uint2*>(stg + r * SS + c * 8 + 4);
           *reinterpret_cast<uint4*>(yb + (size_t)r * a.Cout + c * 8) = uint4{lo.x, lo.y, hi.x, hi.y};
