@@ -156,19 +156,22 @@ struct DwArgs {
   int N, H, W, C, Ho, Wo, pad, act, strips;                               // strips = ceil(Wo / XS) per output row
   int CW, IMG;                                                            // channels per workgroup (blockIdx.z chunk), images per workgroup
   int pool_slots;                                                         // = gridDim.x: partial-sum rows per image in `pool`
+  unsigned x_bytes;                                                       // size of x (range of the buffer loads)
 };
 
-// one input row of a strip: branch-free (always a valid address, zeros selected afterwards)
+// one input row of a strip through range-checked buffer loads: a tap outside the image gets an offset past the buffer and
+// the hardware returns zeros -- one add and one select per load instead of a clamped 64-bit address plus four selects on
+// the loaded dwords (these kernels are instruction-issue bound)
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 template <int NC>
-__device__ __forceinline__ void dw_load_row(u16x8 (&v)[NC], const u16* __restrict__ xn, int iy, int ix0, int H, int W, int C) {
+__device__ __forceinline__ void dw_load_row(u16x8 (&v)[NC], __amdgpu_buffer_rsrc_t rs, unsigned img_off, int iy, int H, unsigned row_bytes,
+                                            const unsigned (&coff)[NC], const bool (&cok)[NC]) {
   const bool rok = iy >= 0 && iy < H;
-  const u16* __restrict__ xr = xn + (size_t)(rok ? iy : 0) * W * C;
+  const unsigned roff = img_off + (unsigned)(rok ? iy : 0) * row_bytes;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    const int ix = ix0 + c;
-    const bool ok = rok && ix >= 0 && ix < W;
-    v[c] = *reinterpret_cast<const u16x8*>(xr + (size_t)(ok ? ix : 0) * C);
-    if (!ok) v[c] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned off = (rok && cok[c]) ? roff + coff[c] : 0xFFFFFFF0u;
+    v[c] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
   }
 }
 
@@ -195,6 +198,8 @@ k_mb_dw(const DwArgs a) {
   }
   for (int t = threadIdx.x; t < CW; t += 256) wl[K * K * CW + ((t >> 2) & 1) * hoff + (t >> 3) * gp + (t & 3)] = a.bias[c0 + t];
   __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(a.x), 0, (unsigned)a.x_bytes, 0x00020000);
+  const unsigned row_bytes = (unsigned)a.W * C * 2u;
   const int per_wg = 256 / CGW;                                   // strips per workgroup pass (CGW <= 72 -> >= 3)
   const int cg = threadIdx.x % CGW, pl = threadIdx.x / CGW;
   const int nitems = a.Ho * a.strips;
@@ -202,11 +207,19 @@ k_mb_dw(const DwArgs a) {
   for (int im = 0; im < a.IMG; ++im) {
     const int n = blockIdx.y * a.IMG + im;
     if (n >= a.N) break;                                          // uniform over the workgroup
-    const u16* __restrict__ xn = a.x + (size_t)n * a.H * a.W * C + c0 + cg * 8;
+    const unsigned img_off = ((unsigned)n * a.H * a.W * C + c0 + cg * 8) * 2u;      // byte offsets: the tensor is below 4 GB (host check)
     float psum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (pl < per_wg) {
       for (int it = blockIdx.x * per_wg + pl; it < nitems; it += gridDim.x * per_wg) {
         const int oy = it / a.strips, ox0 = (it - oy * a.strips) * XS;
+        unsigned coff[NC];
+        bool cok[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int ix = ox0 * S - a.pad + c;
+          cok[c] = ix >= 0 && ix < a.W;
+          coff[c] = (unsigned)(cok[c] ? ix : 0) * (unsigned)C * 2u;
+        }
         // channel pairs ride in packed fp32 FMAs (v_pk_fma_f32): acc[q][h] = channels 2h, 2h+1 of output column q
         f32x2v acc[XS][4];
         {
@@ -221,7 +234,7 @@ k_mb_dw(const DwArgs a) {
 #pragma unroll 1                                                  // one row of taps at a time: ~120 VGPRs, 4 waves per SIMD hide the loads
         for (int ky = 0; ky < K; ++ky) {
           u16x8 v[NC];
-          dw_load_row<NC>(v, xn, oy * S - a.pad + ky, ox0 * S - a.pad, a.H, a.W, C);
+          dw_load_row<NC>(v, rs, img_off, oy * S - a.pad + ky, a.H, row_bytes, coff, cok);
           f32x2v xv[NC][4];
 #pragma unroll
           for (int c = 0; c < NC; ++c)
@@ -615,6 +628,8 @@ extern "C" int fdet_mb_depthwise(const void* x, const float* w, const float* bia
   DwArgs a;
   a.x = (const u16*)x; a.w = w; a.bias = bias; a.y = (u16*)y; a.pool = pool;
   a.N = N; a.H = H; a.W = W; a.C = C; a.act = act;
+  FDET_REQUIRE((size_t)N * H * W * C * 2 < 0xFFFF0000ull, "mb_depthwise: input tensor beyond the 4 GB range of 32-bit buffer offsets");
+  a.x_bytes = (unsigned)((size_t)N * H * W * C * 2);
   a.Ho = (H + stride - 1) / stride; a.Wo = (W + stride - 1) / stride;
   // stride 1: symmetric K/2.  stride 2: TF "SAME": total = max((Ho-1)*2 + K - H, 0), the smaller half in front
   a.pad = stride == 1 ? K / 2 : std::max((a.Ho - 1) * 2 + K - H, 0) / 2;
