@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+SUSTAINED_BF16_MFMA_TFLOPS = 1780.0     # measured, see roofline.frac_of_sustained_bf16_mfma
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 # SURVEY.md 8d, PoolResnet F=64 @480^2 S=10, per image: compulsory activation traffic fwd+bwd and FLOPs
@@ -288,6 +289,9 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_l // args.steps,
                 "algorithmic_mb_per_launch": round(nb / 1e6, 1), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
                 "mfma_passes_per_mac": mf_mult,
+                # the rate this chip SUSTAINS on random bf16 operands under its power limit (tools/probe/mfma_shapes.py,
+                # profiles/r02_c_mfma_shapes.json: 1.78 PFLOP/s of 32x32x16 MFMAs at ~2.0 GHz) -- context, not the roof
+                "frac_of_sustained_bf16_mfma": round(mf_mult * fl / (avg_ms * 1e-3) / 1e12 / SUSTAINED_BF16_MFMA_TFLOPS, 4) if x3 else None,
                 "hbm_frac": round(nb / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if nb else None}
         out = {
             "metric": "train imgs/sec (PoolResnet 480^2, bs=256 per GPU)", "value": round(value, 1), "unit": "imgs/s",
