@@ -421,17 +421,23 @@ __device__ __forceinline__ void apass(T& d) {
 // + L2-resident loads +0.00, + split VALU +0.04, + LDS writes +0.04, + real HBM traffic +0.07 -> 0.56.
 // LPR = lanes per staged row (16, or 32 for one-float lanes of rows up to 32 columns: the 30x30 layers -- their
 // two-float form made hipcc spill accumulators around the 64-bit staging tuples); P = LPR * VW.
-template <int VW, int DBG = 0, int LPR = 16>
+// PK4 (rows of P-3..P floats, P = LPR = 16 or 32, VW = 4): the LPR lanes of a channel slot are 4 rows x P/4 float4 quads instead
+// of LPR columns -- a row is staged with P/4 16-byte loads (the last quad loaded P - W elements early and shifted into place,
+// zeros behind the row's end) instead of W dword loads, 32/P register slots per thread and channel slot (rows rsub + 4 j):
+// a quarter of the load / split / LDS-write instructions of the one-float form, which was issue-bound on the 15x15 layers
+// (0.344 -> 0.283 ms for the 16 layers).
+template <int VW, int DBG = 0, int LPR = 16, int PK4 = 0>
 __global__ void __launch_bounds__(NTHR, 1)
 k_wgrad3x3_x3_pipe(const WgX3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CPP = NTHR / LPR;                      // channels per staging pass (16 or 8)
   constexpr int MTC = 2, MB = 64, ZCH = MB / CPP, XCH = 32 / CPP;
-  constexpr int RZ = 128 / (LPR * VW);                  // dz rows per band held in registers (= R)
+  constexpr int RZ = PK4 ? 32 / LPR : 128 / (LPR * VW); // dz row slots per thread and channel slot (= R unless PK4)
   constexpr int RX = RZ + 2;
   using VT = typename Vec<VW>::T;
   // compile-time tile geometry (plan_x3 computes the same numbers; the launcher checks them)
-  constexpr int P = LPR * VW, R = RZ, KEXT = 144, QZ = KEXT + 24, PX = KEXT + 2 * P + 8;
+  constexpr int P = PK4 ? LPR : LPR * VW, R = PK4 ? 128 / LPR : RZ, KEXT = 144, QZ = KEXT + 24, PX = KEXT + 2 * P + 8;
+  constexpr int QPR = P / 4;                            // PK4: quads per row
   static_assert(R * P == 128 && (QZ / 8) % 2 == 1 && (PX / 8) % 2 == 1, "band = 128 positions, odd 16-byte row pitches");
   constexpr int tile_elems = MB * QZ * 2 + 32 * PX * 2;          // bf16 elements per tile (hi + lo, Z then X)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -455,7 +461,12 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   constexpr int p8 = P / 8;
   const int xv = tid & (LPR - 1), chl = tid / LPR;
-  const bool lane_ok = xv < W / VW;
+  const int rsub = PK4 ? xv / QPR : 0, qd = xv % QPR;             // PK4: row within a group of four, quad within the row
+  const int ecol = PK4 ? qd * 4 : xv * VW;                        // first LDS column of this lane's elements
+  const int lcol = PK4 ? min(qd * 4, W - 4) : xv * VW;            // first column it loads (the last quad starts early)
+  const int shq = ecol - lcol;                                    // ... and is shifted by this many elements
+  const bool lane_ok = PK4 ? true : xv < W / VW;
+#define WGP_ROW(r_) (PK4 ? rsub + 4 * (r_) : (r_))
   const int co0 = cob * MB, ci0 = cib * 32;
   const int HW = a.H * W;
   float bpart[ZCH];
@@ -485,18 +496,18 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
   {                                                                                               \
     if ((L) < NZJ) {                                                                              \
       const int c_ = (L) / RZ, r_ = (L) % RZ;                                                 \
-      const int v = (V0) + r_;                                                                    \
+      const int v = (V0) + WGP_ROW(r_);                                                           \
       const int n = (int)__umulhi((unsigned)min(v, a.VR), a.magic_h1), yy = v - n * H1 - 1;       \
       const bool ok = v < a.VR && yy >= 0 && lane_ok && zch_ok[c_];                               \
-      const unsigned off = ((unsigned)(((DBG & 8) ? 0 : n) * a.Cout * a.H + yy) * W + xv * VW) * 4u + zch_off[c_];  \
+      const unsigned off = ((unsigned)(((DBG & 8) ? 0 : n) * a.Cout * a.H + yy) * W + lcol) * 4u + zch_off[c_];  \
       aload<VW, S == 0>(pz##S[c_][r_], ok ? off : 0x80000000u, rz);                               \
     } else {                                                                                      \
       const int l2_ = (L) - NZJ < NXJ ? (L) - NZJ : 0;                                        \
       const int c_ = l2_ / RZ, r_ = 2 + l2_ % RZ;                                             \
-      const int v = (V0) - 1 + r_;                                                                \
+      const int v = (V0) + 1 + WGP_ROW(l2_ % RZ);                                                 \
       const int n = (int)__umulhi((unsigned)min(max(v, 0), a.VR), a.magic_h1), yy = v - n * H1 - 1; \
       const bool ok = v >= 0 && v < a.VR && yy >= 0 && lane_ok && xch_ok[c_];                     \
-      const unsigned off = ((unsigned)(((DBG & 8) ? 0 : n) * a.Cin * a.H + yy) * W + xv * VW) * 4u + xch_off[c_];   \
+      const unsigned off = ((unsigned)(((DBG & 8) ? 0 : n) * a.Cin * a.H + yy) * W + lcol) * 4u + xch_off[c_];   \
       aload<VW, S == 0>(px##S[c_][r_], ok ? off : 0x80000000u, rx);                               \
     }                                                                                             \
   }
@@ -517,14 +528,15 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
     __bf16* tb_ = base + (TB) * tile_elems;                                                       \
     if ((J) < NZJ) {                                                                              \
       const int c_ = (J) / RZ, r_ = (J) % RZ;                                                 \
-      __bf16* zh_ = tb_ + (c_ * CPP + chl) * QZ + ZP + r_ * P + xv * VW;                         \
-      put_split_pk<VW, DBG>(zh_, zh_ + MB * QZ, pz##S[c_][r_]);                                            \
-      _Pragma("unroll") for (int k_ = 0; k_ < VW; ++k_) bpart[c_] += vget<VW>(pz##S[c_][r_], k_); \
+      __bf16* zh_ = tb_ + (c_ * CPP + chl) * QZ + ZP + WGP_ROW(r_) * P + ecol;                    \
+      const VT t_ = pk_shift<VW, PK4 != 0>(pz##S[c_][r_], shq);                                    \
+      put_split_pk<VW, DBG>(zh_, zh_ + MB * QZ, t_);                                              \
+      _Pragma("unroll") for (int k_ = 0; k_ < VW; ++k_) bpart[c_] += vget<VW>(t_, k_);            \
     } else {                                                                                      \
       const int j2_ = (J) - NZJ < NXJ ? (J) - NZJ : 0;                                        \
       const int c_ = j2_ / RZ, r_ = 2 + j2_ % RZ;                                                 \
-      __bf16* xh_ = tb_ + 2 * MB * QZ + (c_ * CPP + chl) * PX + XP + r_ * P + xv * VW;         \
-      put_split_pk<VW, DBG>(xh_, xh_ + 32 * PX, px##S[c_][r_]);                                            \
+      __bf16* xh_ = tb_ + 2 * MB * QZ + (c_ * CPP + chl) * PX + XP + (2 + WGP_ROW(j2_ % RZ)) * P + ecol; \
+      put_split_pk<VW, DBG>(xh_, xh_ + 32 * PX, pk_shift<VW, PK4 != 0>(px##S[c_][r_], shq));      \
     }                                                                                             \
   }
   // operand fragments of one 16-position MFMA step, two sets (the reads of step s+1 are issued inside step s)
@@ -550,7 +562,7 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
   // slot U (0 .. 31: eight per MFMA step, behind tap groups 1..8) of a band: its jobs, then its loads
 #define WGP_SLOT(S, U, V0N)                                                                       \
   {                                                                                               \
-    if ((U) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < NCP; ++i_) cpy[i_] = *reinterpret_cast<const bf16x8*>(base + (1 - (S)) * tile_elems + cp_off[i_] + RZ * P); } \
+    if ((U) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < NCP; ++i_) cpy[i_] = *reinterpret_cast<const bf16x8*>(base + (1 - (S)) * tile_elems + cp_off[i_] + R * P); } \
     if ((U) == 2) { _Pragma("unroll") for (int i_ = 0; i_ < NCP; ++i_) *reinterpret_cast<bf16x8*>(base + (S) * tile_elems + cp_off[i_]) = cpy[i_]; } \
     _Pragma("unroll") for (int q_ = 0; q_ < JPS; ++q_) {                                          \
       if (!(DBG & 1) && (U) * JPS + q_ < NJ) WGP_JOB(S, ((U) * JPS + q_ < NJ ? (U) * JPS + q_ : 0), S) \
@@ -595,8 +607,8 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
       const int n = (int)__umulhi((unsigned)min(max(v, 0), a.VR), a.magic_h1), yy = v - n * H1 - 1;
 #pragma unroll
       for (int c = 0; c < XCH; ++c) {
-        const bool ok = b0 && v >= 0 && v < a.VR && yy >= 0 && lane_ok && xch_ok[c];
-        aload<VW, false>(hx[c][r], ok ? ((unsigned)(n * a.Cin * a.H + yy) * W + xv * VW) * 4u + xch_off[c] : 0x80000000u, rx);
+        const bool ok = b0 && v >= 0 && v < a.VR && yy >= 0 && lane_ok && xch_ok[c] && (!PK4 || rsub == r);
+        aload<VW, false>(hx[c][r], ok ? ((unsigned)(n * a.Cin * a.H + yy) * W + lcol) * 4u + xch_off[c] : 0x80000000u, rx);
       }
     }
 #pragma unroll
@@ -610,8 +622,8 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
   for (int c = 0; c < XCH; ++c)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      __bf16* xh_ = base + 2 * MB * QZ + (c * CPP + chl) * PX + XP + r * P + xv * VW;
-      put_split<VW>(xh_, xh_ + 32 * PX, 0, hx[c][r]);
+      __bf16* xh_ = base + 2 * MB * QZ + (c * CPP + chl) * PX + XP + r * P + ecol;
+      if (!PK4 || rsub == r) put_split<VW>(xh_, xh_ + 32 * PX, 0, pk_shift<VW, PK4 != 0>(hx[c][r], shq));
     }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) WGP_JOB(0, j, 0)
@@ -650,6 +662,7 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
 #undef WGP_JOB
 #undef WGP_WAIT
 #undef WGP_LOAD1
+#undef WGP_ROW
   // ---- combine the K halves through LDS, one slab per workgroup (as the base kernel)
   __syncthreads();
   {
@@ -732,7 +745,7 @@ k_wgx3_reduce(const float* __restrict__ ws_all, const float* __restrict__ wsb_al
 
 unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
-struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw, NSEG, CW, pack, pipe, lpr32; size_t lds, ws_floats; bool ok; };
+struct WgX3Plan { int P, VR, R, QZ, PX, Kext, nbands, nblk, MTC, CoP, CiP, vw, NSEG, CW, pack, pipe, lpr32, pk4; size_t lds, ws_floats; bool ok; };
 
 WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   WgX3Plan p{};
@@ -779,6 +792,11 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
     p.pipe = p.ok && p.MTC == 2 && p.NSEG == 1 && !p.pack && ((p.vw != 2 && rp * p.P == 128) || lpr32) && rows_total >= 8 &&
              (size_t)N * std::max(Cin, Cout) * H * W < ((size_t)1 << 29) && !(e && e[0] == '0');   // 32-bit byte offsets
     p.lpr32 = p.pipe && lpr32;
+    {
+      const char* e4 = getenv("FDET_WGRAD_PK4");
+      // rows of 13..16 floats (one-float form, 16 lanes) or 29..32 floats (the 32-lane form): float4 quads instead
+      p.pk4 = p.pipe && !(e4 && e4[0] == '0') && ((!p.lpr32 && p.vw == 1 && W >= 13 && W <= 16 && p.P == 16) || (p.lpr32 && W >= 29 && p.P == 32));
+    }
     if (p.pipe) bestR = p.lpr32 ? 4 : rp;      // -> Kext 144, QZ 168, PX 152 + 2 P: the kernel's compile-time geometry
   }
   p.R = bestR;
@@ -809,7 +827,9 @@ void launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) 
 #define WG_DBG_CASE(D) if (dbg == D && !p.lpr32) { if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4, D>); else go(k_wgrad3x3_x3_pipe<1, D>); return; }
     WG_DBG_CASE(1) WG_DBG_CASE(3) WG_DBG_CASE(8) WG_DBG_CASE(9) WG_DBG_CASE(24) WG_DBG_CASE(40) WG_DBG_CASE(73)
 #endif
-    if (p.lpr32) go(k_wgrad3x3_x3_pipe<1, 0, 32>);
+    if (p.lpr32 && p.pk4) go(k_wgrad3x3_x3_pipe<4, 0, 32, 1>);
+    else if (p.lpr32) go(k_wgrad3x3_x3_pipe<1, 0, 32>);
+    else if (p.pk4) go(k_wgrad3x3_x3_pipe<4, 0, 16, 1>);
     else if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4>);
     else go(k_wgrad3x3_x3_pipe<1>);
   } else if (p.NSEG > 1) go(k_wgrad3x3_x3<MTC, 4, true>);

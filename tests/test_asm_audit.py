@@ -15,8 +15,11 @@ CSRC = os.path.join(ROOT, "pytorch-face-detection-from-scratch_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 KERNELS = {
-    "fdet_wgrad3x3_x3.hip": ["_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi16E", "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi1ELi0ELi16E",
-                             "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi1ELi0ELi32E"],
+    # <VW, DBG, LPR, PK4>: 60x60 (float4 lanes), 15x15 and 30x30 (float4 quads of narrow rows: the shipped path), and the
+    # one-float forms they replace for rows of 13..16 / 29..32 floats (still used for other widths)
+    "fdet_wgrad3x3_x3.hip": ["_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi16ELi0E", "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi16ELi1E",
+                             "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi32ELi1E", "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi1ELi0ELi16ELi0E",
+                             "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi1ELi0ELi32ELi0E"],
     "fdet_stem_x3.hip": ["_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipe", "_ZN12_GLOBAL__N_120k_stem_wgrad_x3_pipe"],
 }
 
