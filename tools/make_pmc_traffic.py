@@ -12,9 +12,9 @@ import bench
 # group -> regex over "<kernel> grid=<n>" (one symbol per group in the headline model; the two data-gradient epilogue
 # flavours of a resolution are one group)
 GROUPS = {
-    "conv3x3_wgrad@60x60": r"k_wgrad3x3_x3_pipe<4, 0, 16>",
-    "conv3x3_wgrad@30x30": r"k_wgrad3x3_x3_pipe<1, 0, 32>",
-    "conv3x3_wgrad@15x15": r"k_wgrad3x3_x3_pipe<1, 0, 16>",
+    "conv3x3_wgrad@60x60": r"k_wgrad3x3_x3_pipe<4, 0, 16, 0>",
+    "conv3x3_wgrad@30x30": r"k_wgrad3x3_x3_pipe<4, 0, 32, 1>",
+    "conv3x3_wgrad@15x15": r"k_wgrad3x3_x3_pipe<4, 0, 16, 1>",
     "conv3x3_fwd@60x60": r"k_conv3x3_x3_sb<2, 2, 4, 1, true>",
     "conv3x3_fwd_pool@60x60": r"k_conv3x3_x3_sb<2, 2, 4, 6, true>",
     "conv3x3_dgrad@60x60": r"k_conv3x3_x3_sb<2, 2, 4, 4, true>",
