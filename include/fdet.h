@@ -288,6 +288,30 @@ int fdet_conv3x3_dgrad_unpool_bf16x3(const float* dz, const void* wpk, const flo
 int fdet_pool_route_bwd(const float* dout_pooled, const unsigned char* route, const float* drop_scale, float* dz2,
                         int N, int F, int H, int W, float slope, void* stream);
 
+/* Engine-private PRE-SPLIT ("PS") activations of the bf16x3 conv stack (csrc/fdet_ps.h): a feature map [N,C,H,W]
+ * (C % 8 == 0, W <= 62) kept as bf16 hi | lo planes with 8 channels innermost, rows padded to 16/32/64 slots with
+ * zero halo slots, zero rows between images -- the layout the MFMA operands have in LDS, so the conv kernels stage
+ * it with LDS-DMA and their epilogues write it for the next consumer.  Same bytes per element as fp32.  No
+ * counterpart in the reference (its tensors are fp32 NCHW: models/PoolResnet.py:33-43); fp32 NCHW stays the format at
+ * every C-ABI boundary that mirrors a reference interface.
+ *   fdet_ps_bytes          allocation size in bytes (includes one all-zero guard image on either side; the caller
+ *                          zero-fills the allocation ONCE, producers write real elements only); 0 = unsupported shape
+ *   fdet_ps_image0_offset  byte offset of image 0 inside the allocation: the pointer every other call takes
+ *   fdet_ps_from_f32 / fdet_ps_to_f32   converters (value = float(hi) + float(lo), 16 significant bits) */
+size_t fdet_ps_bytes(int N, int C, int H, int W);
+size_t fdet_ps_image0_offset(int N, int C, int H, int W);
+int fdet_ps_from_f32(const float* x, void* ps, int N, int C, int H, int W, void* stream);
+int fdet_ps_to_f32(const void* ps, float* x, int N, int C, int H, int W, void* stream);
+/* 3x3 convs on PS tensors (Cout == 64, Cin % 16 == 0, maps of 15..62 columns); wpk: forward / backward panels of
+ * fdet_pack_conv3x3_weights_bf16x3.  Same arithmetic as fdet_conv3x3_fwd_bf16x3 / fdet_conv3x3_dgrad_bf16x3
+ * (models/PoolResnet.py:33-36 and its autograd):
+ *   fwd      : y_ps  = LeakyReLU(conv(x_ps) + bias)
+ *   dgrad_act: dx_ps = conv^T(dz_ps) * LeakyReLU'(act_ps) */
+int fdet_conv3x3_ps_fwd(const void* x_ps, const void* wpk, const float* bias, void* y_ps, int N, int Cin, int Cout,
+                        int H, int W, float slope, void* stream);
+int fdet_conv3x3_ps_dgrad_act(const void* dz_ps, const void* wpk, const void* act_ps, void* dx_ps, int N, int Cin,
+                              int Cout, int H, int W, float slope, void* stream);
+
 /* Pointwise (1x1) convolution / per-position Linear layer as a dense GEMM on the matrix cores, bf16x3 arithmetic
  * (fp32-level accuracy).  Replaces nn.Conv2d(Cin, Cout, 1) of SeparableResidualBlock.pointwise_conv_skip
  * (models/SSD.py:24-30) and nn.Linear(C, 5) applied at every position (models/SSD.py:183-185) and their autograd.

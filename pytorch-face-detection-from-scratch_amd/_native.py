@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # imported BEFORE the CDLL so that libamdhip64.so.7 resolves to torch's runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfdet_hip.so")
+LIB_PATH = os.environ.get("FDET_LIB_PATH") or os.path.join(_HERE, "lib", "libfdet_hip.so")   # override: development builds (tools/probe)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fdet.h")
 
 
@@ -72,6 +72,12 @@ SIGNATURES = {
     "fdet_conv3x3_fwd_pool_bf16x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_dgrad_unpool_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_pool_route_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "fdet_ps_bytes": (_SZ, [_I, _I, _I, _I]),
+    "fdet_ps_image0_offset": (_SZ, [_I, _I, _I, _I]),
+    "fdet_ps_from_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fdet_ps_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fdet_conv3x3_ps_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_ps_dgrad_act": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_pointwise_packed_bytes": (_SZ, [_I, _I]),
     "fdet_pack_pointwise_weights_bf16x3": (_I, [_P, _I, _I, _P, _P, _P]),
     "fdet_pointwise_fwd_bf16x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

@@ -1,0 +1,79 @@
+// Pre-split (PS) activation format: allocation geometry and the fp32 NCHW <-> PS converters (fdet_ps.h).
+// The converters sit at the boundary of the PS region of the conv stack (and in the tests); inside the region the
+// producing epilogues write PS directly.
+#include "fdet_ps.h"
+
+using namespace fdet;
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+k_ps_from_f32(const float* __restrict__ x, ps_bf16x8* __restrict__ ps, PsGeo g, int total) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int xx = t % g.W, r = t / g.W;
+  const int y = r % g.H, r2 = r / g.H;
+  const int gr = r2 % g.C8, n = r2 / g.C8;
+  const size_t HW = (size_t)g.H * g.W;
+  const float* src = x + ((size_t)n * g.C + gr * 8) * HW + (size_t)y * g.W + xx;
+  ps_bf16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float f = src[j * HW];
+    const __bf16 h = (__bf16)f;
+    hi[j] = h;
+    lo[j] = (__bf16)(f - (float)h);
+  }
+  const size_t u = (size_t)n * g.img + (size_t)(gr * g.HP + y) * g.WP + xx + 1;
+  ps[u] = hi;
+  ps[u + g.plane] = lo;
+}
+
+__global__ void __launch_bounds__(256)
+k_ps_to_f32(const ps_bf16x8* __restrict__ ps, float* __restrict__ x, PsGeo g, int total) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int xx = t % g.W, r = t / g.W;
+  const int y = r % g.H, r2 = r / g.H;
+  const int gr = r2 % g.C8, n = r2 / g.C8;
+  const size_t HW = (size_t)g.H * g.W;
+  const size_t u = (size_t)n * g.img + (size_t)(gr * g.HP + y) * g.WP + xx + 1;
+  const ps_bf16x8 hi = ps[u], lo = ps[u + g.plane];
+  float* dst = x + ((size_t)n * g.C + gr * 8) * HW + (size_t)y * g.W + xx;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dst[j * HW] = (float)hi[j] + (float)lo[j];
+}
+
+}  // namespace
+
+extern "C" size_t fdet_ps_bytes(int N, int C, int H, int W) {
+  PsGeo g;
+  if (!ps_geo(N, C, H, W, g)) return 0;
+  return (size_t)(N + 2) * g.img * 16;
+}
+
+extern "C" size_t fdet_ps_image0_offset(int N, int C, int H, int W) {
+  PsGeo g;
+  if (!ps_geo(N, C, H, W, g)) return 0;
+  return (size_t)g.img * 16;
+}
+
+extern "C" int fdet_ps_from_f32(const float* x, void* ps, int N, int C, int H, int W, void* stream) {
+  PsGeo g;
+  FDET_REQUIRE(x && ps && ps_geo(N, C, H, W, g), "ps_from_f32: unsupported shape N=%d C=%d H=%d W=%d", N, C, H, W);
+  const long long total = (long long)N * g.C8 * H * W;
+  FDET_REQUIRE(total < (1ll << 31), "ps_from_f32: tensor too large");
+  hipLaunchKernelGGL(k_ps_from_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<ps_bf16x8*>(ps), g, (int)total);
+  return check_launch("fdet_ps_from_f32");
+}
+
+extern "C" int fdet_ps_to_f32(const void* ps, float* x, int N, int C, int H, int W, void* stream) {
+  PsGeo g;
+  FDET_REQUIRE(x && ps && ps_geo(N, C, H, W, g), "ps_to_f32: unsupported shape N=%d C=%d H=%d W=%d", N, C, H, W);
+  const long long total = (long long)N * g.C8 * H * W;
+  FDET_REQUIRE(total < (1ll << 31), "ps_to_f32: tensor too large");
+  hipLaunchKernelGGL(k_ps_to_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const ps_bf16x8*>(ps), x, g, (int)total);
+  return check_launch("fdet_ps_to_f32");
+}

@@ -1,0 +1,84 @@
+"""Engine-private pre-split (PS) activations of the bf16x3 conv stack (csrc/fdet_ps.h, include/fdet.h).
+
+A `PsTensor` owns ONE zero-filled allocation (two guard images included) and hands the C-ABI the pointer of
+image 0.  Producers only ever write real elements, so the halo slots / rows / guard images stay zero for the life
+of the buffer -- which is why the engine keeps these buffers across steps instead of re-allocating them.
+
+No counterpart in the reference (its tensors are fp32 NCHW, models/PoolResnet.py:33-43): fp32 NCHW remains the
+format at every boundary that mirrors a reference interface.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._native import FdetError, check, lib, ptr, stream
+
+F32 = torch.float32
+
+
+class PsTensor:
+    """bf16 hi|lo planes of a (N,C,H,W) feature map, 8 channels innermost, zero halos (see csrc/fdet_ps.h)."""
+
+    def __init__(self, N: int, C: int, H: int, W: int, device):
+        nbytes = int(lib().fdet_ps_bytes(N, C, H, W))
+        if nbytes == 0:
+            raise FdetError(f"PsTensor: unsupported shape ({N},{C},{H},{W}) (C % 8 == 0, W <= 62 required)")
+        self.shape = (N, C, H, W)
+        self.buf = torch.zeros(nbytes // 4, dtype=F32, device=device)        # zeroed ONCE
+        self._off = int(lib().fdet_ps_image0_offset(N, C, H, W))
+
+    @property
+    def data(self) -> int:
+        """Device pointer of image 0 (what every fdet_*_ps_* entry point takes)."""
+        return ptr(self.buf) + self._off
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    @classmethod
+    def from_f32(cls, x: torch.Tensor, out: "PsTensor" = None) -> "PsTensor":
+        if x.dim() != 4 or x.dtype != F32 or not x.is_contiguous():
+            raise TypeError("PsTensor.from_f32: expected a contiguous fp32 (N,C,H,W) tensor")
+        N, C, H, W = x.shape
+        t = out if out is not None else cls(N, C, H, W, x.device)
+        if t.shape != (N, C, H, W):
+            raise ValueError(f"PsTensor.from_f32: buffer is {t.shape}, tensor is {tuple(x.shape)}")
+        check(lib().fdet_ps_from_f32(ptr(x), t.data, N, C, H, W, stream()), "fdet_ps_from_f32")
+        return t
+
+    def to_f32(self, out: torch.Tensor = None) -> torch.Tensor:
+        N, C, H, W = self.shape
+        y = out if out is not None else torch.empty(N, C, H, W, dtype=F32, device=self.device)
+        if tuple(y.shape) != self.shape:
+            raise ValueError("PsTensor.to_f32: output shape mismatch")
+        check(lib().fdet_ps_to_f32(self.data, ptr(y), N, C, H, W, stream()), "fdet_ps_to_f32")
+        return y
+
+
+def _same(a: PsTensor, shape, name):
+    if not isinstance(a, PsTensor) or a.shape != tuple(shape):
+        raise ValueError(f"{name}: expected a PsTensor of shape {tuple(shape)}, got {getattr(a, 'shape', type(a))}")
+
+
+def conv3x3_ps_fwd(x: PsTensor, wpk: torch.Tensor, bias: torch.Tensor, y: PsTensor, slope: float = 0.2) -> None:
+    """y = LeakyReLU(conv3x3(x) + bias) on PS tensors; wpk: forward panel of pack_conv3x3_weights(x3=True)."""
+    N, cin, H, W = x.shape
+    cout = int(bias.shape[0])
+    _same(y, (N, cout, H, W), "conv3x3_ps_fwd: y")
+    if wpk.numel() != cout * cin * 9:
+        raise ValueError("conv3x3_ps_fwd: packed weight size does not match (Cout,Cin)")
+    check(lib().fdet_conv3x3_ps_fwd(x.data, ptr(wpk), ptr(bias), y.data, N, cin, cout, H, W, float(slope), stream()),
+          "fdet_conv3x3_ps_fwd")
+
+
+def conv3x3_ps_dgrad_act(dz: PsTensor, wpk_bwd: torch.Tensor, act: PsTensor, dx: PsTensor, slope: float = 0.2) -> None:
+    """dx = conv3x3^T(dz) * LeakyReLU'(act) on PS tensors; wpk_bwd: backward panel."""
+    N, cout, H, W = dz.shape
+    cin = dx.shape[1]
+    _same(dx, (N, cin, H, W), "conv3x3_ps_dgrad_act: dx")
+    _same(act, (N, cin, H, W), "conv3x3_ps_dgrad_act: act")
+    if wpk_bwd.numel() != cout * cin * 9:
+        raise ValueError("conv3x3_ps_dgrad_act: packed weight size does not match (Cout,Cin)")
+    check(lib().fdet_conv3x3_ps_dgrad_act(dz.data, ptr(wpk_bwd), act.data, dx.data, N, cin, cout, H, W, float(slope),
+                                          stream()), "fdet_conv3x3_ps_dgrad_act")

@@ -1,0 +1,77 @@
+"""GPU parity of the pre-split (PS) activation path (csrc/fdet_ps.h, fdet_conv3x3_ps.hip): format round trip and the
+PS conv kernels against a plain PyTorch fp32 CPU reference of the same op (tolerance 1e-4 of the tensor's scale, as
+everywhere; the PS format itself keeps 16 significant bits: |x - (hi+lo)| <= 2^-16 |x|)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import fdet_amd
+    from fdet_amd import hotpath, ps
+    return hotpath, ps
+
+
+def close(a, b, tol=1e-4):
+    a = a.cpu().double(); b = b.cpu().double()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"max err {err} vs scale {scale}"
+
+
+# (N, C, H, W): the PoolResnet maps, odd / short maps, a single image, more images than one band run covers
+PS_SHAPES = [(3, 64, 60, 60), (5, 64, 30, 30), (1, 64, 60, 60), (2, 64, 12, 56), (9, 64, 16, 30), (2, 64, 7, 17)]
+
+
+@pytest.mark.parametrize("shape", PS_SHAPES + [(2, 16, 15, 15), (1, 8, 3, 5)])
+def test_ps_round_trip_and_zero_halos(env, shape):
+    hp, ps = env
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(N, C, H, W, generator=g) * torch.exp(torch.randn(N, C, H, W, generator=g) * 3)
+    x[0, 0, 0, 0] = 0.0
+    t = ps.PsTensor.from_f32(x.cuda())
+    y = t.to_f32().cpu()
+    assert torch.all((y - x).abs() <= x.abs() * 2.0 ** -16)
+    # everything that is not a real element is still zero: sum of |bits| over the buffer == sum over the real elements
+    raw = t.buf.view(torch.int16).cpu()
+    nz = int((raw != 0).sum())
+    t2 = ps.PsTensor(N, C, H, W, "cuda")
+    ps.PsTensor.from_f32(torch.ones(N, C, H, W, device="cuda"), out=t2)
+    real = int((t2.buf.view(torch.int16).cpu() != 0).sum())          # ones: hi != 0, lo == 0 -> one word per element
+    assert real == N * C * H * W
+    assert nz <= 2 * N * C * H * W
+
+
+@pytest.mark.parametrize("shape", PS_SHAPES)
+def test_conv3x3_ps_fwd_and_dgrad(env, shape):
+    hp, ps = env
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    nf, nb = hp.packed_sizes(C, C)
+    wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda")
+    hp.pack_conv3x3_weights(w.cuda(), wf, wb, x3=True)
+    xp = ps.PsTensor.from_f32(x.cuda())
+    xr = xp.to_f32().cpu()                                   # the input as the PS format holds it
+    yp = ps.PsTensor(N, C, H, W, "cuda")
+    ps.conv3x3_ps_fwd(xp, wf, b.cuda(), yp, slope=0.2)
+    z = F.leaky_relu(F.conv2d(xr, w, b, padding=1), 0.2)
+    close(yp.to_f32(), z)
+    # the halos of the OUTPUT are untouched zeros (a consumer relies on them)
+    real = ps.PsTensor.from_f32(torch.full((N, C, H, W), 1.0 + 2.0 ** -9, device="cuda"))    # hi and lo both non-zero
+    outside = real.buf.view(torch.int16) == 0
+    assert int((yp.buf.view(torch.int16)[outside] != 0).sum()) == 0
+    # data gradient with the LeakyReLU derivative of a saved activation
+    dz = torch.randn(N, C, H, W, generator=g)
+    act = torch.randn(N, C, H, W, generator=g)
+    dzp = ps.PsTensor.from_f32(dz.cuda()); ap = ps.PsTensor.from_f32(act.cuda())
+    dxp = ps.PsTensor(N, C, H, W, "cuda")
+    ps.conv3x3_ps_dgrad_act(dzp, wb, ap, dxp, slope=0.2)
+    ref = F.conv_transpose2d(dzp.to_f32().cpu(), w, padding=1) * torch.where(act > 0, 1.0, 0.2)
+    close(dxp.to_f32(), ref)
