@@ -312,6 +312,14 @@ int fdet_conv3x3_ps_fwd(const void* x_ps, const void* wpk, const float* bias, vo
 int fdet_conv3x3_ps_dgrad_act(const void* dz_ps, const void* wpk, const void* act_ps, void* dx_ps, int N, int Cin,
                               int Cout, int H, int W, float slope, void* stream);
 
+/* Weight / bias gradients of L same-shape 64-channel 3x3 layers from PS tensors (h_x[l], h_dz[l]: host arrays of
+ * image-0 device pointers): dW[l] [64,64,3,3], db[l] [64] (autograd of models/PoolResnet.py:33-36; same results as
+ * fdet_conv3x3_wgrad_bf16x3_batched to the rounding of the PS format).  ws: fdet_conv3x3_wgrad_ps_ws_bytes bytes
+ * (0 = unsupported shape).  Deterministic (fixed-order slab reduction). */
+size_t fdet_conv3x3_wgrad_ps_ws_bytes(int L, int N, int C, int H, int W);
+int fdet_conv3x3_wgrad_ps_batched(const void* const* h_x, const void* const* h_dz, float* const* h_dW, float* const* h_db,
+                                  int L, int N, int C, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
 /* Pointwise (1x1) convolution / per-position Linear layer as a dense GEMM on the matrix cores, bf16x3 arithmetic
  * (fp32-level accuracy).  Replaces nn.Conv2d(Cin, Cout, 1) of SeparableResidualBlock.pointwise_conv_skip
  * (models/SSD.py:24-30) and nn.Linear(C, 5) applied at every position (models/SSD.py:183-185) and their autograd.

@@ -78,6 +78,8 @@ SIGNATURES = {
     "fdet_ps_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fdet_conv3x3_ps_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_ps_dgrad_act": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_wgrad_ps_ws_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "fdet_conv3x3_wgrad_ps_batched": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "fdet_pointwise_packed_bytes": (_SZ, [_I, _I]),
     "fdet_pack_pointwise_weights_bf16x3": (_I, [_P, _I, _I, _P, _P, _P]),
     "fdet_pointwise_fwd_bf16x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

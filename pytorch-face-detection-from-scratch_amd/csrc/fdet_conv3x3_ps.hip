@@ -14,6 +14,7 @@
 // within a chunk), results agree with those kernels to the rounding of the PS format (16 significant bits).
 #include "fdet_conv3x3_x3.h"
 #include "fdet_ps.h"
+#include "fdet_ldsdma.h"
 #include <algorithm>
 
 using namespace fdet;
@@ -25,7 +26,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 #ifndef PS_DBG
-#define PS_DBG 0          // development builds (-DPS_DBG=n, timing only): 1 = no epilogue, 2 = no MFMAs, 4 = no DMA
+#define PS_DBG 0          // development builds (-DPS_DBG=n, timing only): 1 = no epilogue, 2 = no MFMAs, 4 = no DMA, 8 = every activation DMA from image 0 (L2-resident), 16 = no weight DMA
 #endif
 constexpr int PSA = 9 * 2 * 64;      // weight units per plane (hi / lo) and 16-channel chunk: [tap][k half][64 co]
 constexpr int PS_ROWI = 10;          // DMA wave-instructions per activation array and chunk: (R + 2) * WP / 64 <= 10
@@ -46,9 +47,75 @@ struct PsConvArgs {
   float slope;
 };
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// timing builds: keeps an accumulator tile (and the MFMAs that feed it) alive without storing it
+__device__ __forceinline__ void ps_keep(const f32x16& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::"v"(v));
+#endif
+}
+
+// One epilogue unit: accumulator tile (m, n), group pair gp (channels 32m + 16gp .. + 15 at the lane's position).
+// lane = position, registers = channels 32m + 8g + 4half + i; a v_permlane32_swap pair leaves every lane with all 8
+// channels of ONE 16-byte unit (lanes 0-31: group 2gp, lanes 32-63: group 2gp+1), so a unit is two 16-byte buffer
+// stores (hi, lo), 512 contiguous bytes per wave-instruction.  The validity of the position is folded into the offset
+// (out of range = dropped by the hardware): every wave issues exactly two stores per unit, which the counted waits
+// of the main loop rely on.
+template <int MODE>
+__device__ __forceinline__ void ps_unit(const f32x16& acc, const int gp, const float (&bza)[4], const float (&bzb)[4],
+                                        const u32x2_t (&sg)[4], const float slope, const bool ok, const int ob, const int m,
+                                        const int half, const int gstride, const int plane_o_bytes,
+                                        const __amdgpu_buffer_rsrc_t yrs) {
+  float za[4], zb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // explicit accumulation-register reads: the finished tile stays in AGPRs until the unit that consumes it (left to
+    // itself hipcc moves the whole previous tile into 128 VGPRs at the tile boundary and spills around it)
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass silently drops a kernel whose body holds device-only asm constraints)
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(za[i]) : "a"(acc[8 * gp + i]));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(zb[i]) : "a"(acc[8 * gp + 4 + i]));
+#else
+    za[i] = acc[8 * gp + i]; zb[i] = acc[8 * gp + 4 + i];
+#endif
+  }
+  if (MODE == PSE_FWD_FULL) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float wa = za[i] + bza[i], wb = zb[i] + bzb[i];
+      za[i] = fmaxf(wa, wa * slope);                     // == w > 0 ? w : w*slope for 0 <= slope <= 1 (NaN stays NaN)
+      zb[i] = fmaxf(wb, wb * slope);
+    }
+  } else if (MODE == PSE_DGRAD_ACT) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      za[i] *= ps_join(sg[0][i >> 1], sg[1][i >> 1], i & 1) > 0.f ? 1.f : slope;
+      zb[i] *= ps_join(sg[2][i >> 1], sg[3][i >> 1], i & 1) > 0.f ? 1.f : slope;
+    }
+  }
+  unsigned ha[2], la[2], hb[2], lb[2];
+  ps_split4(za, ha, la);
+  ps_split4(zb, hb, lb);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    auto r1 = __builtin_amdgcn_permlane32_swap(ha[k], hb[k], false, false);
+    ha[k] = r1[0]; hb[k] = r1[1];
+    auto r2 = __builtin_amdgcn_permlane32_swap(la[k], lb[k], false, false);
+    la[k] = r2[0]; lb[k] = r2[1];
+  }
+  const int G = 4 * m + 2 * gp + half;
+  const unsigned off = ok ? (unsigned)(ob + G * gstride) * 16u : 0x80000000u;
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4{ha[0], ha[1], hb[0], hb[1]}, yrs, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(u32x4{la[0], la[1], lb[0], lb[1]}, yrs, off, plane_o_bytes, 0);
+}
+
+// WOVEN (forward): the epilogue of tile i runs as 16 "units" spread over the first two chunks of tile i+1, one unit
+// behind each of taps 0..7, its ~65 VALU instructions and two stores placed two or three per MFMA gap by
+// sched_group_barrier; two accumulator sets alternate.  The other modes keep the epilogue at the end of the tile.
 template <int MODE, int WP>
 __global__ void __launch_bounds__(256, 1)
 k_conv3x3_ps(const PsConvArgs p) {
+  constexpr bool WOVEN = MODE == PSE_FWD_FULL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16x8* const lds = reinterpret_cast<bf16x8*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -73,40 +140,45 @@ k_conv3x3_ps(const PsConvArgs p) {
   }
   if (tile >= tend) return;
 
-  // per-lane source offsets (units, without the array base) of the activation DMA instructions of a tile
-  int ro[PS_ROWI];
+  // per-lane source byte offsets (relative to the guard image in front of image 0, without the array base) of the
+  // activation DMA pieces of a tile
+  unsigned ro[PS_ROWI];
 #define PS_ROWOFF(T)                                                                               \
   {                                                                                                \
-    const int v0_ = (T) * R;                                                                     \
+    const int v0_ = (T) * R;                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < PS_ROWI; ++i_) {                                       \
       const int u_ = i_ * 64 + lane;                                                               \
-      const int vv_ = v0_ - 1 + (u_ >> WPL) + HP;                                                \
+      const int vv_ = v0_ - 1 + (u_ >> WPL) + HP;                                                  \
       const int nn_ = (int)__umulhi((unsigned)vv_, p.magic_hp);                                    \
-      ro[i_] = (nn_ - 1) * p.img_i + (vv_ - nn_ * HP) * WP + (u_ & (WP - 1));                      \
+      ro[i_] = (unsigned)(((PS_DBG & 8) ? 1 : nn_) * p.img_i + (vv_ - nn_ * HP) * WP + (u_ & (WP - 1))) * 16u; \
     }                                                                                              \
   }
-  // DMA of chunk C of the tile whose offsets are in ro[] into buffer BS: wave w moves weight plane w >> 1, half
-  // w & 1 (nine 1-KiB pieces) and activation array w = (plane, k half) (NBI pieces)
+  // DMA of chunk C of the tile whose offsets are in ro[] into buffer BS (fdet_ldsdma.h): wave w moves weight plane
+  // w >> 1, half w & 1 (nine 1-KiB pieces) and activation array w = (plane, k half) (NBI pieces)
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t)smem;
+  const dma_u32x4 wrs = dma_rsrc((wid >> 1) ? p.a_lo : p.a_hi, (unsigned)p.nch * PSA * 16u);
+  const dma_u32x4 xrs = dma_rsrc(p.x - p.img_i, (unsigned)(p.N + 2) * (unsigned)p.img_i * 16u);
+  const unsigned wvoff = (unsigned)((wid & 1) * 576 + lane) * 16u;
 #define PS_DMA(C, BS)                                                                              \
-  if (!(PS_DBG & 4)) {                                                                              \
-    bf16x8* db_ = lds + (BS) * buf_units;                                                          \
-    const bf16x8* as_ = ((wid >> 1) ? p.a_lo : p.a_hi) + (size_t)(C) * PSA + (wid & 1) * 576 + lane; \
-    bf16x8* ad_ = db_ + (wid >> 1) * PSA + (wid & 1) * 576;                                        \
-    _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_)                                               \
-      __builtin_amdgcn_global_load_lds((glb_void_t)(as_ + k_ * 64), (lds_void_t)(ad_ + k_ * 64), 16, 0, 0); \
-    const bf16x8* bs_ = p.x + (size_t)(wid >> 1) * p.plane_i + (size_t)(2 * (C) + (wid & 1)) * HP * WP; \
-    bf16x8* bd_ = db_ + 2 * PSA + wid * PT;                                                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < PS_ROWI; ++i_)                                         \
-      if (i_ < NBI) __builtin_amdgcn_global_load_lds((glb_void_t)(bs_ + ro[i_]), (lds_void_t)(bd_ + i_ * 64), 16, 0, 0); \
+  if (!(PS_DBG & 4)) {                                                                             \
+    const unsigned db_ = lds0 + (unsigned)(BS) * (buf_units * 16);                                 \
+    const unsigned ad_ = db_ + (unsigned)((wid >> 1) * PSA + (wid & 1) * 576) * 16u;               \
+    _Pragma("unroll") for (int k_ = 0; k_ < ((PS_DBG & 16) ? 0 : 9); ++k_)                          \
+      dma_piece(ad_ + k_ * 1024, wvoff, wrs, (unsigned)(C) * (PSA * 16) + k_ * 1024);              \
+    const unsigned bso_ = (unsigned)((wid >> 1) * p.plane_i + (2 * (C) + (wid & 1)) * HP * WP) * 16u; \
+    const unsigned bd_ = db_ + (unsigned)(2 * PSA + wid * PT) * 16u;                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < NBI; ++i_) dma_piece(bd_ + i_ * 1024, ro[i_], xrs, bso_); \
   }
 
-  f32x16 acc[2][4];
+  f32x16 accA[2][4], accB[WOVEN ? 2 : 1][WOVEN ? 4 : 1];
+  if (WOVEN) {
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < 4; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        for (int r = 0; r < 16; ++r) accB[WOVEN ? m : 0][WOVEN ? n : 0][r] = 0.f;   // the first tile's "previous tile": nothing is stored from it
+  }
 
   // this lane's bias values: channel 32m + 8g + 4half + i
   float bz[2][4][4];
@@ -119,29 +191,48 @@ k_conv3x3_ps(const PsConvArgs p) {
 
   const int a_off = half * 64 + l31;                     // + tap*128 + m*32 ; lo plane: + PSA
   const int b_off = 2 * PSA + half * PT + l31;           // + qn[n] + tap offset ; lo planes: + 2*PT
-
+  const int gstride = HP * WP, plane_o_bytes = p.plane_o * 16;
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.N * p.img_o * 16), 0x00020000);
-  bool stored = false;                                   // the previous tile's 32 epilogue stores may still be in flight
-  PS_ROWOFF(tile)
-  PS_DMA(0, 0)
+
+  // output geometry of a tile: unit index of (group 0, this lane's position) per n block, and its validity
+  int ob[4];
+  bool okn[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { ob[n] = 0; okn[n] = false; }
+#define PS_GEO(T)                                                                                  \
+  {                                                                                                \
+    _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                                             \
+      const int q_ = qn[n_] + l31;                                                                 \
+      const int col_ = q_ & (WP - 1);                                                              \
+      const int v_ = (T) * R + (q_ >> WPL);                                                        \
+      const int nn_ = (int)__umulhi((unsigned)v_, p.magic_hp), y_ = v_ - nn_ * HP;                 \
+      okn[n_] = nn_ < p.N && y_ < p.H && col_ < p.W;                                               \
+      ob[n_] = nn_ * p.img_o + y_ * WP + col_ + 1;                                                 \
+    }                                                                                              \
+  }
+  const u32x2_t sg0[4] = {};                             // placeholder of the sign operand in the forward mode
+
+  int young = 0;                                         // stores of this wave younger than its last DMA: 0, 16 or 32
   int sb = 0;
-  for (; tile < tend; tile += tstep) {
-    const int v0 = tile * R;
-    for (int c = 0; c < p.nch; ++c) {
-      // chunk c of this tile has landed (it was issued a whole chunk ago; the epilogue's stores are younger)
-      if (c == 0 && stored) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                      // ... in every wave, and the other buffer is free
-      if (c + 1 < p.nch) {
-        PS_DMA(c + 1, sb ^ 1)
-      } else if (tile + tstep < tend) {
-        PS_ROWOFF(tile + tstep)
-        PS_DMA(0, sb ^ 1)
-      }
-      const bf16x8* buf = lds + sb * buf_units;
-      const bf16x8* Aw = buf + a_off;
-      const bf16x8* Bw = buf + b_off;
-      bf16x8 ah[2][2], al[2][2], bh[2][4], bl[2][4];
+  // a chunk opens when its DMA (issued a whole chunk ago; only `young` stores are younger) has landed in every wave
+#define PS_OPEN()                                                                                  \
+  {                                                                                                \
+    if (young == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                             \
+    else if (young == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                        \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+    __builtin_amdgcn_s_barrier();                                                                  \
+  }
+#define PS_NEXT(C)                                                                                 \
+  {                                                                                                \
+    if ((C) + 1 < p.nch) {                                                                         \
+      PS_DMA((C) + 1, sb ^ 1)                                                                      \
+    } else if (tile + tstep < tend) {                                                              \
+      PS_ROWOFF(tile + tstep)                                                                      \
+      PS_DMA(0, sb ^ 1)                                                                            \
+    }                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  }
+  bf16x8 ah[2][2], al[2][2], bh[2][4], bl[2][4];
 #define PS_FRAGS(F, T)                                                                             \
   {                                                                                                \
     const int to_ = ((T) / 3) * WP + (T) % 3;                                                      \
@@ -154,124 +245,118 @@ k_conv3x3_ps(const PsConvArgs p) {
       bl[F][n_] = Bw[2 * PT + qn[n_] + to_];                                                       \
     }                                                                                              \
   }
-      __builtin_amdgcn_sched_barrier(0);
-      PS_FRAGS(0, 0)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int F = t & 1;
-        if (t < 8) PS_FRAGS(F ^ 1, t + 1)
-        if (!(PS_DBG & 2)) {
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[F][m], bl[F][n], acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[F][m], bh[F][n], acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[F][m], bh[F][n], acc[m][n], 0, 0, 0);
-            }
-        }
-        // the next tap's twelve fragment reads ride one per MFMA on the first half of this tap
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-      }
-#undef PS_FRAGS
-      sb ^= 1;
-    }
-    // ---- epilogue: lane = position, registers = channels 32m + 8g + 4half + i.  A v_permlane32_swap pair makes
-    // a lane hold all 8 channels of one unit: 16-byte stores, 512 contiguous bytes per wave-instruction.  Stores are
-    // buffer stores with the validity folded into the offset (out of range = dropped): every wave issues exactly 32,
-    // which is what the counted wait at the head of the next tile relies on.  Every load precedes the first store.
-    if (!(PS_DBG & 1)) {
-      int ob[4];
-      bool okn[4];
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int q = qn[n] + l31;
-        const int col = q & (WP - 1);
-        const int v = v0 + (q >> WPL);
-        const int nn = (int)__umulhi((unsigned)v, p.magic_hp), y = v - nn * HP;
-        okn[n] = nn < p.N && y < p.H && col < p.W;
-        ob[n] = nn * p.img_o + y * WP + col + 1;                 // + G*HP*WP (+ plane_o)
-      }
-      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-      u32x2_t sg[MODE == PSE_DGRAD_ACT ? 4 : 1][2][2][4];
-      if (MODE == PSE_DGRAD_ACT) {
-        // the saved activation: this lane's 4 channels (8 bytes) of groups 4m+2gp and 4m+2gp+1, hi and lo
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          const u32x2_t* ap = reinterpret_cast<const u32x2_t*>(p.aux + (okn[n] ? ob[n] : 0)) + half;
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-              const size_t ga = (size_t)(4 * m + 2 * gp) * HP * WP, gb = ga + (size_t)HP * WP;
-              sg[n][m][gp][0] = ap[ga * 2];
-              sg[n][m][gp][1] = ap[(ga + p.plane_o) * 2];
-              sg[n][m][gp][2] = ap[gb * 2];
-              sg[n][m][gp][3] = ap[(gb + p.plane_o) * 2];
-            }
-        }
-      }
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int gp = 0; gp < 2; ++gp) {
-            float za[4], zb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { za[i] = acc[m][n][8 * gp + i]; zb[i] = acc[m][n][8 * gp + 4 + i]; }
-            if (MODE == PSE_FWD_FULL) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const float wa = za[i] + bz[m][2 * gp][i], wb = zb[i] + bz[m][2 * gp + 1][i];
-                za[i] = fmaxf(wa, wa * p.slope);
-                zb[i] = fmaxf(wb, wb * p.slope);
-              }
-            } else if (MODE == PSE_DGRAD_ACT) {
-              const int sn = MODE == PSE_DGRAD_ACT ? n : 0;
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                za[i] *= ps_join(sg[sn][m][gp][0][i >> 1], sg[sn][m][gp][1][i >> 1], i & 1) > 0.f ? 1.f : p.slope;
-                zb[i] *= ps_join(sg[sn][m][gp][2][i >> 1], sg[sn][m][gp][3][i >> 1], i & 1) > 0.f ? 1.f : p.slope;
-              }
-            }
-            unsigned ha[2], la[2], hb[2], lb[2];
-            ps_split4(za, ha, la);
-            ps_split4(zb, hb, lb);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              auto r1 = __builtin_amdgcn_permlane32_swap(ha[k], hb[k], false, false);
-              ha[k] = r1[0]; hb[k] = r1[1];
-              auto r2 = __builtin_amdgcn_permlane32_swap(la[k], lb[k], false, false);
-              la[k] = r2[0]; lb[k] = r2[1];
-            }
-            const int G = 4 * m + 2 * gp + half;
-            const unsigned off = okn[n] ? (unsigned)(ob[n] + G * HP * WP) * 16u : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ha[0], ha[1], hb[0], hb[1]}, yrs, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{la[0], la[1], lb[0], lb[1]}, yrs, off, p.plane_o * 16, 0);
-          }
-      }
-      stored = true;
-    }
-    if (PS_DBG & 1) {                                    // timing builds: keep the accumulators (and their MFMAs) alive
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(acc[m][n]));
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  // nine taps of one chunk into ACC; FIRST: the tile's first chunk (the first product of every accumulator takes a
+  // zero C operand: no clearing pass); JOB 1 / 2: epilogue units of blocks n = 0,1 / 2,3 of PREV behind taps 0..7
+#define PS_BODY(ACC, FIRST, JOB, PREV)                                                             \
+  {                                                                                                \
+    const bf16x8* buf_ = lds + sb * buf_units;                                                     \
+    const bf16x8* Aw = buf_ + a_off;                                                               \
+    const bf16x8* Bw = buf_ + b_off;                                                               \
+    PS_FRAGS(0, 0)                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                \
+      const int F = t & 1;                                                                         \
+      if (t < 8) PS_FRAGS(F ^ 1, t + 1)                                                            \
+      if (!(PS_DBG & 2)) {                                                                         \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                              \
+          _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                          \
+            const f32x16 zero_ = {};                                                               \
+            ACC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[F][m], bl[F][n], ((FIRST) && t == 0) ? zero_ : ACC[m][n], 0, 0, 0); \
+            ACC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[F][m], bh[F][n], ACC[m][n], 0, 0, 0); \
+            ACC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[F][m], bh[F][n], ACC[m][n], 0, 0, 0); \
+          }                                                                                        \
+      }                                                                                            \
+      if ((JOB) != 0 && t < 8 && !(PS_DBG & 1)) {                                                  \
+        const int n_ = ((JOB) - 1) * 2 + (t >> 2), m_ = (t >> 1) & 1, gp_ = t & 1;                 \
+        ps_unit<MODE>(PREV[WOVEN ? m_ : 0][WOVEN ? n_ : 0], gp_, bz[m_][2 * gp_], bz[m_][2 * gp_ + 1], sg0, p.slope, okn[n_], ob[n_], m_, \
+                      half, gstride, plane_o_bytes, yrs);                                          \
+      }                                                                                            \
+      /* the next tap's twelve fragment reads ride one per MFMA on the first half of this tap, the unit's VALU  */ \
+      /* work three per gap, its two stores near the end                                                        */ \
+      _Pragma("unroll") for (int i = 0; i < 12; ++i) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+        if ((JOB) != 0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                         \
+      }                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 12; ++i) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        if ((JOB) != 0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                         \
+        if ((JOB) != 0 && i >= 10) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);              \
+      }                                                                                            \
+    }                                                                                              \
+    sb ^= 1;                                                                                       \
   }
+  // the whole epilogue of ACC (geometry in ob / okn) at once: every load precedes the first store
+#define PS_EPILOGUE(ACC)                                                                           \
+  if (!(PS_DBG & 1)) {                                                                             \
+    u32x2_t sg[MODE == PSE_DGRAD_ACT ? 4 : 1][2][2][4];                                            \
+    if (MODE == PSE_DGRAD_ACT) {                                                                   \
+      /* the saved activation: this lane's 4 channels (8 bytes) of groups 4m+2gp and 4m+2gp+1, hi and lo */ \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                              \
+        const u32x2_t* ap = reinterpret_cast<const u32x2_t*>(p.aux + (okn[n] ? ob[n] : 0)) + half; \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                              \
+          _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                       \
+            const size_t ga = (size_t)(4 * m + 2 * gp) * gstride, gb = ga + (size_t)gstride;       \
+            sg[n][m][gp][0] = ap[ga * 2];                                                          \
+            sg[n][m][gp][1] = ap[(ga + p.plane_o) * 2];                                            \
+            sg[n][m][gp][2] = ap[gb * 2];                                                          \
+            sg[n][m][gp][3] = ap[(gb + p.plane_o) * 2];                                            \
+          }                                                                                        \
+      }                                                                                            \
+    }                                                                                              \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                  \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
+        _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                           \
+          ps_unit<MODE>(ACC[m][n], gp, bz[m][2 * gp], bz[m][2 * gp + 1], sg[MODE == PSE_DGRAD_ACT ? n : 0][m][gp], p.slope, \
+                        okn[n], ob[n], m, half, gstride, plane_o_bytes, yrs);                      \
+  } else {                                                                                         \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n) ps_keep(ACC[m][n]);                            \
+  }
+  // one tile into ACC
+#define PS_TILE(ACC, PREV)                                                                         \
+  {                                                                                                \
+    PS_OPEN()                                                                                      \
+    PS_NEXT(0)                                                                                     \
+    PS_BODY(ACC, 1, (WOVEN ? 1 : 0), PREV)                                                         \
+    young = (WOVEN && !(PS_DBG & 1)) ? 16 : 0;                                                     \
+    PS_OPEN()                                                                                      \
+    PS_NEXT(1)                                                                                     \
+    PS_BODY(ACC, 0, (WOVEN ? 2 : 0), PREV)                                                         \
+    for (int c = 2; c < p.nch; ++c) {                                                              \
+      PS_OPEN()                                                                                    \
+      PS_NEXT(c)                                                                                   \
+      PS_BODY(ACC, 0, 0, PREV)                                                                     \
+      young = 0;                                                                                   \
+    }                                                                                              \
+    PS_GEO(tile)                                                                                   \
+    if (!WOVEN) {                                                                                  \
+      PS_EPILOGUE(ACC)                                                                             \
+      young = (PS_DBG & 1) ? 0 : 32;                                                               \
+    }                                                                                              \
+  }
+
+  PS_ROWOFF(tile)
+  PS_DMA(0, 0)
+  if (WOVEN) {
+    for (;;) {
+      PS_TILE(accA, accB)
+      tile += tstep;
+      if (tile >= tend) { PS_EPILOGUE(accA) break; }
+      PS_TILE(accB, accA)
+      tile += tstep;
+      if (tile >= tend) { PS_EPILOGUE(accB) break; }
+    }
+  } else {
+    for (; tile < tend; tile += tstep) PS_TILE(accA, accA)
+  }
+#undef PS_TILE
+#undef PS_EPILOGUE
+#undef PS_BODY
+#undef PS_FRAGS
+#undef PS_NEXT
+#undef PS_OPEN
+#undef PS_GEO
 #undef PS_DMA
 #undef PS_ROWOFF
 }
@@ -304,7 +389,7 @@ int run_ps(int mode, const void* x, const void* wpk, const float* bias, const vo
            int H, int W, float slope, hipStream_t st) {
   PsGeo gi, go;
   FDET_REQUIRE(x && wpk && y, "conv3x3_ps: null pointer");
-  FDET_REQUIRE(Cout == 64 && Cin % 16 == 0 && Cin >= 16, "conv3x3_ps: Cout must be 64 and Cin a multiple of 16 (Cin=%d Cout=%d)", Cin, Cout);
+  FDET_REQUIRE(Cout == 64 && Cin % 16 == 0 && Cin >= 32, "conv3x3_ps: Cout must be 64 and Cin a multiple of 16 (Cin=%d Cout=%d)", Cin, Cout);
   FDET_REQUIRE(ps_geo(N, Cin, H, W, gi) && ps_geo(N, Cout, H, W, go) && gi.WP >= 32, "conv3x3_ps: unsupported map %dx%d", H, W);
   FDET_REQUIRE(slope >= 0.f && slope <= 1.f, "conv3x3_ps: slope must be in [0, 1]");
   PsConvArgs p;

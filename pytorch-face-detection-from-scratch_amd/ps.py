@@ -82,3 +82,23 @@ def conv3x3_ps_dgrad_act(dz: PsTensor, wpk_bwd: torch.Tensor, act: PsTensor, dx:
         raise ValueError("conv3x3_ps_dgrad_act: packed weight size does not match (Cout,Cin)")
     check(lib().fdet_conv3x3_ps_dgrad_act(dz.data, ptr(wpk_bwd), act.data, dx.data, N, cin, cout, H, W, float(slope),
                                           stream()), "fdet_conv3x3_ps_dgrad_act")
+
+
+def conv3x3_wgrad_ps_ws_bytes(L: int, N: int, C: int, H: int, W: int) -> int:
+    return int(lib().fdet_conv3x3_wgrad_ps_ws_bytes(L, N, C, H, W))
+
+
+def conv3x3_wgrad_ps_batched(xs, dzs, dWs, dbs, ws: torch.Tensor) -> None:
+    """dWs[l] (64,64,3,3), dbs[l] (64,) = weight / bias gradients of L same-shape layers from PS operands."""
+    import ctypes
+    L = len(xs)
+    N, C, H, W = xs[0].shape
+    for x, dz, dW, db in zip(xs, dzs, dWs, dbs):
+        _same(x, (N, C, H, W), "conv3x3_wgrad_ps: x")
+        _same(dz, (N, C, H, W), "conv3x3_wgrad_ps: dz")
+        if tuple(dW.shape) != (C, C, 3, 3) or tuple(db.shape) != (C,):
+            raise ValueError("conv3x3_wgrad_ps: dW / db shapes")
+    arr = ctypes.c_void_p * L
+    check(lib().fdet_conv3x3_wgrad_ps_batched(arr(*[x.data for x in xs]), arr(*[z.data for z in dzs]),
+                                              arr(*[ptr(t) for t in dWs]), arr(*[ptr(t) for t in dbs]), L, N, C, H, W,
+                                              ptr(ws), ws.numel() * 4, stream()), "fdet_conv3x3_wgrad_ps_batched")

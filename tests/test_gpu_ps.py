@@ -75,3 +75,30 @@ def test_conv3x3_ps_fwd_and_dgrad(env, shape):
     ps.conv3x3_ps_dgrad_act(dzp, wb, ap, dxp, slope=0.2)
     ref = F.conv_transpose2d(dzp.to_f32().cpu(), w, padding=1) * torch.where(act > 0, 1.0, 0.2)
     close(dxp.to_f32(), ref)
+
+
+@pytest.mark.parametrize("shape", PS_SHAPES)
+@pytest.mark.parametrize("L", [1, 2])
+def test_conv3x3_wgrad_ps(env, shape, L):
+    hp, ps = env
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(N * 77 + H + W + L)
+    xs = [torch.randn(N, C, H, W, generator=g) for _ in range(L)]
+    dzs = [torch.randn(N, C, H, W, generator=g) for _ in range(L)]
+    xp = [ps.PsTensor.from_f32(x.cuda()) for x in xs]
+    zp = [ps.PsTensor.from_f32(z.cuda()) for z in dzs]
+    dW = [torch.full((C, C, 3, 3), float("nan"), device="cuda") for _ in range(L)]
+    db = [torch.full((C,), float("nan"), device="cuda") for _ in range(L)]
+    nb = ps.conv3x3_wgrad_ps_ws_bytes(L, N, C, H, W)
+    assert nb > 0
+    ws = torch.empty(nb // 4, device="cuda")
+    ps.conv3x3_wgrad_ps_batched(xp, zp, dW, db, ws)
+    for l in range(L):
+        xr, zr = xp[l].to_f32().cpu().double(), zp[l].to_f32().cpu().double()
+        ref_w = torch.nn.grad.conv2d_weight(xr, (C, C, 3, 3), zr, padding=1)
+        close(dW[l], ref_w)
+        close(db[l], zr.sum(dim=(0, 2, 3)))
+    # bit-reproducible
+    dW2 = [torch.empty_like(t) for t in dW]; db2 = [torch.empty_like(t) for t in db]
+    ps.conv3x3_wgrad_ps_batched(xp, zp, dW2, db2, ws)
+    assert all(torch.equal(a, b) for a, b in zip(dW + db, dW2 + db2))

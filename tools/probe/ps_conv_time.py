@@ -43,3 +43,24 @@ for (N, H) in ((256, 60), (256, 30)):
     flops = 2.0 * N * C * C * 9 * H * H * 3
     out[f"{H}x{H}"] = {k: {"median_ms": v[0], "min_ms": v[1], "pflops_bf16_passes": round(flops / (v[0] * 1e-3) / 1e15, 3)} for k, v in r.items()}
 print(json.dumps(out, indent=1))
+
+# ---- weight gradient: PS kernel vs the register-staged pipeline, 2 layers at 60x60 / 30x30 as in the training step
+wout = {}
+for (N, H) in ((256, 60), (256, 30)):
+    C, L = 64, 2
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(N, C, H, H, generator=g).cuda() for _ in range(L)]
+    zs = [torch.randn(N, C, H, H, generator=g).cuda() for _ in range(L)]
+    xp = [ps.PsTensor.from_f32(t) for t in xs]; zp = [ps.PsTensor.from_f32(t) for t in zs]
+    dW = [torch.empty(C, C, 3, 3, device="cuda") for _ in range(L)]; db = [torch.empty(C, device="cuda") for _ in range(L)]
+    ws_ps = torch.empty(ps.conv3x3_wgrad_ps_ws_bytes(L, N, C, H, H) // 4, device="cuda")
+    ws_old = torch.empty(hp.conv3x3_wgrad_batched_ws_bytes(L, N, C, C, H, H) // 4, device="cuda")
+    fns = {"wgrad_f32io": lambda: hp.conv3x3_wgrad_batched(xs, zs, dW, db, ws_old),
+           "wgrad_ps": lambda: ps.conv3x3_wgrad_ps_batched(xp, zp, dW, db, ws_ps)}
+    for f in fns.values():
+        f()
+    torch.cuda.synchronize()
+    r = timeit(fns)
+    flops = 2.0 * L * N * C * C * 9 * H * H * 3
+    wout[f"{H}x{H}"] = {k: {"median_ms": v[0], "min_ms": v[1], "pflops_bf16_passes": round(flops / (v[0] * 1e-3) / 1e15, 3)} for k, v in r.items()}
+print("WGRAD " + json.dumps(wout))
