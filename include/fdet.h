@@ -312,6 +312,21 @@ int fdet_conv3x3_ps_fwd(const void* x_ps, const void* wpk, const float* bias, vo
 int fdet_conv3x3_ps_dgrad_act(const void* dz_ps, const void* wpk, const void* act_ps, void* dx_ps, int N, int Cin,
                               int Cout, int H, int W, float slope, void* stream);
 
+/* Pooled residual block on PS tensors (models/PoolResnet.py:36-42 and its autograd; 64 channels, even maps), the tail
+ * fused into the convolutions as in fdet_conv3x3_fwd_pool_bf16x3 / fdet_conv3x3_dgrad_unpool_bf16x3 / fdet_pool_route_bwd:
+ *   fwd_pool     : pooled = maxpool2x2(lrelu(conv(x_ps)+bias) * drop_scale + skip_ps) -> pool_ps (PS, may be NULL) and / or
+ *                  pool_f32 (fp32 NCHW, may be NULL); route8 [N][8][H/2][W/2][8] uint8 (channel-innermost routing bytes,
+ *                  NULL in eval): bits 0-3 = (c > 0) of the window's four elements in scan order, bits 4-5 = argmax
+ *                  (first maximum wins, NaN is a maximum)
+ *   route_bwd    : dz2_ps = unpool(dout_pooled) * drop_scale * lrelu'(c)        (dout_pooled: fp32 NCHW)
+ *   dgrad_unpool : dx (fp32 NCHW) = conv^T(dz_ps) + unpool(dout_pooled) */
+int fdet_conv3x3_ps_fwd_pool(const void* x_ps, const void* wpk, const float* bias, const void* skip_ps,
+                             const float* drop_scale, void* pool_ps, float* pool_f32, unsigned char* route8, int N, int Cin,
+                             int Cout, int H, int W, float slope, void* stream);
+int fdet_pool_route_bwd_ps(const float* dout_pooled, const unsigned char* route8, const float* drop_scale, void* dz2_ps,
+                           int N, int C, int H, int W, float slope, void* stream);
+int fdet_conv3x3_ps_dgrad_unpool(const void* dz_ps, const void* wpk, const float* dout_pooled, const unsigned char* route8,
+                                 float* dx, int N, int Cin, int Cout, int H, int W, float slope, void* stream);
 /* Weight / bias gradients of L same-shape 64-channel 3x3 layers from PS tensors (h_x[l], h_dz[l]: host arrays of
  * image-0 device pointers): dW[l] [64,64,3,3], db[l] [64] (autograd of models/PoolResnet.py:33-36; same results as
  * fdet_conv3x3_wgrad_bf16x3_batched to the rounding of the PS format).  ws: fdet_conv3x3_wgrad_ps_ws_bytes bytes

@@ -78,6 +78,9 @@ SIGNATURES = {
     "fdet_ps_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fdet_conv3x3_ps_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_ps_dgrad_act": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_ps_fwd_pool": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_pool_route_bwd_ps": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_ps_dgrad_unpool": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_wgrad_ps_ws_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "fdet_conv3x3_wgrad_ps_batched": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "fdet_pointwise_packed_bytes": (_SZ, [_I, _I]),

@@ -31,7 +31,7 @@ namespace {
 constexpr int PSA = 9 * 2 * 64;      // weight units per plane (hi / lo) and 16-channel chunk: [tap][k half][64 co]
 constexpr int PS_ROWI = 10;          // DMA wave-instructions per activation array and chunk: (R + 2) * WP / 64 <= 10
 
-enum { PSE_FWD_FULL = 0, PSE_DGRAD_ACT = 1 };
+enum { PSE_FWD_FULL = 0, PSE_DGRAD_ACT = 1, PSE_FWD_POOL = 2, PSE_DGRAD_ADDPOOL = 3 };
 
 struct PsConvArgs {
   const bf16x8* x;           // PS input, image 0
@@ -39,7 +39,16 @@ struct PsConvArgs {
   const bf16x8* a_lo;
   const float* bias;         // forward modes
   bf16x8* y;                 // PS output, image 0
-  const bf16x8* aux;         // PSE_DGRAD_ACT: PS activation whose sign selects the LeakyReLU slope
+  const bf16x8* aux;         // PSE_DGRAD_ACT: PS activation whose sign selects the LeakyReLU slope; PSE_FWD_POOL: the skip tensor (PS)
+  // pooled-block modes (a lane owns one whole 2x2 window, see POOLM in the kernel)
+  const float* scale;        // FWD_POOL: [N,64] dropout scale or null
+  bf16x8* pool_ps;           // FWD_POOL: pooled output as PS (image 0) or null
+  float* pool_f32;           // FWD_POOL: pooled output as fp32 NCHW or null
+  unsigned char* route_out;  // FWD_POOL: routing bytes [N][8][Hp][Wp][8] or null (eval)
+  const float* dout;         // DGRAD_ADDPOOL: gradient of the pooled block output, fp32 NCHW
+  const unsigned char* route_in;
+  float* dx_f32;             // DGRAD_ADDPOOL: dx, fp32 NCHW
+  int Hp, Wp, HPp, WPp, plane_p, img_p;
   int N, H, W, HP;
   int nch, ntiles;
   int plane_i, img_i, plane_o, img_o;
@@ -53,6 +62,15 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void ps_keep(const f32x16& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" ::"v"(v));
+#endif
+}
+
+// one accumulator element -> VGPR (explicit accumulation-register read, see ps_unit)
+__device__ __forceinline__ void ps_acc_read(const f32x16& acc, const int r, float& z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(z) : "a"(acc[r]));
+#else
+  z = acc[r];
 #endif
 }
 
@@ -128,6 +146,16 @@ k_conv3x3_ps(const PsConvArgs p) {
   int qn[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) qn[n] = WP == 64 ? (2 * wid + (n & 1)) * 64 + (n >> 1) * 32 : (4 * wid + n) * 32;
+  // POOLM (pooled-block modes): a lane's four blocks are the four elements of ONE 2x2 pooling window, in scan order
+  // n = 2*row + column -- block n is (row 2w' + (n >> 1), column 2*lane + (n & 1)) -- so max / argmax / routing byte and
+  // the un-pooling need no cross-lane traffic.  The MFMA does not care which position a column is; the price is a
+  // 32-byte lane stride of the activation fragment reads (2-way LDS bank conflict on 8 of a tap's 12 reads).
+  constexpr bool POOLM = MODE == PSE_FWD_POOL || MODE == PSE_DGRAD_ADDPOOL;
+  if (POOLM) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) qn[n] = (WP == 64 ? (2 * wid + (n >> 1)) * 64 : (4 * wid + (n >> 1)) * 32) + (n & 1);
+  }
+  const int lb = POOLM ? (WP == 64 ? 2 * l31 : 2 * l31 + 32 * (l31 >> 4)) : l31;
   // XCD-aware persistent walk (as fdet_conv3x3_x3_sb.hip): workgroups with equal blockIdx % 8 share an L2 and take
   // one contiguous eighth of the bands, so the halo rows two neighbouring bands share are L2 hits
   int tile = blockIdx.x, tend = p.ntiles, tstep = gridDim.x;
@@ -187,10 +215,10 @@ k_conv3x3_ps(const PsConvArgs p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) bz[m][g][i] = (MODE == PSE_FWD_FULL) ? p.bias[32 * m + 8 * g + 4 * half + i] : 0.f;
+      for (int i = 0; i < 4; ++i) bz[m][g][i] = (MODE == PSE_FWD_FULL || MODE == PSE_FWD_POOL) ? p.bias[32 * m + 8 * g + 4 * half + i] : 0.f;
 
   const int a_off = half * 64 + l31;                     // + tap*128 + m*32 ; lo plane: + PSA
-  const int b_off = 2 * PSA + half * PT + l31;           // + qn[n] + tap offset ; lo planes: + 2*PT
+  const int b_off = 2 * PSA + half * PT + lb;            // + qn[n] + tap offset ; lo planes: + 2*PT
   const int gstride = HP * WP, plane_o_bytes = p.plane_o * 16;
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.N * p.img_o * 16), 0x00020000);
 
@@ -215,10 +243,11 @@ k_conv3x3_ps(const PsConvArgs p) {
   int young = 0;                                         // stores of this wave younger than its last DMA: 0, 16 or 32
   int sb = 0;
   // a chunk opens when its DMA (issued a whole chunk ago; only `young` stores are younger) has landed in every wave
+#define PS_WAITN(K) else if (young == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory");
 #define PS_OPEN()                                                                                  \
   {                                                                                                \
-    if (young == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                             \
-    else if (young == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                        \
+    if (young == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               \
+    PS_WAITN(8) PS_WAITN(12) PS_WAITN(16) PS_WAITN(32) PS_WAITN(36) PS_WAITN(40) PS_WAITN(44) PS_WAITN(63) \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
     __builtin_amdgcn_s_barrier();                                                                  \
   }
@@ -286,9 +315,135 @@ k_conv3x3_ps(const PsConvArgs p) {
     }                                                                                              \
     sb ^= 1;                                                                                       \
   }
+  // ---- pooled-block epilogues (POOLM mapping): geometry of this lane's window in tile T
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(MODE == PSE_FWD_POOL ? (void*)p.pool_ps : (void*)p.dx_f32, 0,
+      MODE == PSE_FWD_POOL ? (int)((size_t)p.N * p.img_p * 16) : (int)((size_t)p.N * 64 * p.H * p.W * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(p.pool_f32, 0, (int)((size_t)p.N * 64 * p.Hp * p.Wp * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(p.route_out, 0, (int)((size_t)p.N * 64 * p.Hp * p.Wp), 0x00020000);
+  const int pool_cnt = MODE == PSE_FWD_POOL ? 4 * (2 * (p.pool_ps != nullptr) + (p.route_out != nullptr) + 8 * (p.pool_f32 != nullptr)) : 63;
+#define PS_WIN(T)                                                                                  \
+    const int rb_ = WP == 64 ? 2 * wid : 4 * wid + 2 * (l31 >> 4);                                 \
+    const int v_ = (T) * R + rb_;                                                                  \
+    const int nn = (int)__umulhi((unsigned)v_, p.magic_hp), y = v_ - nn * HP;                      \
+    const int xp = WP == 64 ? l31 : (l31 & 15), yp = y >> 1;                                       \
+    const bool okw = nn < p.N && y < p.H && 2 * xp < p.W;
+  // maxpool2x2(lrelu(acc + bias) * scale + skip) -> pooled PS / fp32 NCHW, routing bytes.  Every load first; stores are
+  // buffer stores with the validity in the offset (exactly pool_cnt per wave, counted by the next tile's first wait).
+#define PS_EPI_FWD_POOL(ACC, T)                                                                    \
+  if (!(PS_DBG & 1)) {                                                                             \
+    PS_WIN(T)                                                                                      \
+    const int sb0 = okw ? nn * p.img_i + y * WP + 2 * xp + 1 : 0;                                  \
+    u32x2_t sk[2][2][4][4];                                                                        \
+    float scv[2][2][2][4];                                                                         \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                           \
+        const size_t ga = (size_t)(4 * m + 2 * gp) * gstride, gb = ga + (size_t)gstride;           \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                            \
+          const u32x2_t* ap = reinterpret_cast<const u32x2_t*>(p.aux + sb0 + (n >> 1) * WP + (n & 1)) + half; \
+          sk[m][gp][n][0] = ap[ga * 2];                                                            \
+          sk[m][gp][n][1] = ap[(ga + p.plane_i) * 2];                                              \
+          sk[m][gp][n][2] = ap[gb * 2];                                                            \
+          sk[m][gp][n][3] = ap[(gb + p.plane_i) * 2];                                              \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+          const int ch = 32 * m + 16 * gp + 4 * half + i;                                          \
+          scv[m][gp][0][i] = (p.scale && okw) ? p.scale[nn * 64 + ch] : 1.f;                       \
+          scv[m][gp][1][i] = (p.scale && okw) ? p.scale[nn * 64 + ch + 8] : 1.f;                   \
+        }                                                                                          \
+      }                                                                                            \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                           \
+        float pv[2][4];                                                                            \
+        unsigned rt[2] = {0u, 0u};                                                                 \
+        _Pragma("unroll") for (int ab = 0; ab < 2; ++ab)                                           \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+            float mx = -INFINITY;                                                                  \
+            int arg = 0;                                                                           \
+            unsigned bits = 0;                                                                     \
+            _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                        \
+              float z;                                                                             \
+              ps_acc_read(ACC[m][n], 8 * gp + 4 * ab + i, z);                                      \
+              const float w_ = z + bz[m][2 * gp + ab][i];                                          \
+              z = fmaxf(w_, w_ * p.slope);                                                         \
+              bits |= (z > 0.f ? 1u : 0u) << n;                                                    \
+              const float u_ = z * scv[m][gp][ab][i] + ps_join(sk[m][gp][n][2 * ab][i >> 1], sk[m][gp][n][2 * ab + 1][i >> 1], i & 1); \
+              if (u_ > mx || u_ != u_) { mx = u_; arg = n; }   /* first maximum wins, NaN is a maximum (ATen) */ \
+            }                                                                                      \
+            pv[ab][i] = mx;                                                                        \
+            rt[ab] |= (bits | ((unsigned)arg << 4)) << (8 * i);                                    \
+          }                                                                                        \
+        if (p.pool_f32) {   /* this lane's own 8 channels: 32m + 16gp + 8ab + 4half + i */          \
+          const unsigned off = okw ? (unsigned)(((nn * 64 + 32 * m + 16 * gp + 4 * half) * p.Hp + yp) * p.Wp + xp) * 4u : 0x80000000u; \
+          _Pragma("unroll") for (int jj = 0; jj < 8; ++jj)                                         \
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv[jj >> 2][jj & 3]), frs, off, \
+                                                  (8 * (jj >> 2) + (jj & 3)) * p.Hp * p.Wp * 4, 0); \
+        }                                                                                          \
+        /* half exchange: lanes 0-31 keep group 2gp (channels 0-3 own, 4-7 from the upper half), lanes 32-63 group 2gp+1 */ \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+          auto r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(pv[0][i]), __float_as_uint(pv[1][i]), false, false); \
+          const unsigned r0_ = r_[0], r1_ = r_[1];   /* (a bit_cast applied to a vector ELEMENT is miscompiled: copy first) */ \
+          pv[0][i] = __uint_as_float(r0_); pv[1][i] = __uint_as_float(r1_);                        \
+        }                                                                                          \
+        { auto r_ = __builtin_amdgcn_permlane32_swap(rt[0], rt[1], false, false); rt[0] = r_[0]; rt[1] = r_[1]; } \
+        const int G = 4 * m + 2 * gp + half;                                                       \
+        if (p.pool_ps) {                                                                           \
+          unsigned ha[2], la[2], hb[2], lb2[2];                                                    \
+          ps_split4(pv[0], ha, la);                                                                \
+          ps_split4(pv[1], hb, lb2);                                                               \
+          const unsigned off = okw ? (unsigned)(nn * p.img_p + (G * p.HPp + yp) * p.WPp + xp + 1) * 16u : 0x80000000u; \
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{ha[0], ha[1], hb[0], hb[1]}, prs, off, 0, 0); \
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{la[0], la[1], lb2[0], lb2[1]}, prs, off, p.plane_p * 16, 0); \
+        }                                                                                          \
+        if (p.route_out) {                                                                         \
+          const unsigned off = okw ? (unsigned)(((nn * 8 + G) * p.Hp + yp) * p.Wp + xp) * 8u : 0x80000000u; \
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{rt[0], rt[1]}, rrs, off, 0, 0);            \
+        }                                                                                          \
+      }                                                                                            \
+  } else {                                                                                         \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n) ps_keep(ACC[m][n]);                            \
+  }
+  // dx = acc + unpool(dout) through the routing bytes -> fp32 NCHW, one 8-byte store per (channel, row)
+#define PS_EPI_ADDPOOL(ACC, T)                                                                     \
+  if (!(PS_DBG & 1)) {                                                                             \
+    PS_WIN(T)                                                                                      \
+    float dg[2][2][2][4];                                                                          \
+    unsigned rk[2][2][2];                                                                          \
+    const int HWp = p.Hp * p.Wp;                                                                   \
+    const int pbase = okw ? (nn * 64 * p.Hp + yp) * p.Wp + xp : 0;                                 \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                             \
+        _Pragma("unroll") for (int ab = 0; ab < 2; ++ab) {                                         \
+          const int G = 4 * m + 2 * gp + ab;                                                       \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) dg[m][gp][ab][i] = okw ? p.dout[pbase + (8 * G + 4 * half + i) * HWp] : 0.f; \
+          rk[m][gp][ab] = okw ? *reinterpret_cast<const unsigned*>(p.route_in + (size_t)(((nn * 8 + G) * p.Hp + yp) * p.Wp + xp) * 8 + 4 * half) : 0u; \
+        }                                                                                          \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                             \
+        _Pragma("unroll") for (int ab = 0; ab < 2; ++ab)                                           \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+            const int ch = 32 * m + 16 * gp + 8 * ab + 4 * half + i;                               \
+            const int arg = (int)((rk[m][gp][ab] >> (8 * i + 4)) & 3u);                            \
+            const float gv = dg[m][gp][ab][i];                                                     \
+            _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                        \
+              float z0, z1;                                                                        \
+              ps_acc_read(ACC[m][2 * r], 8 * gp + 4 * ab + i, z0);                                 \
+              ps_acc_read(ACC[m][2 * r + 1], 8 * gp + 4 * ab + i, z1);                             \
+              z0 += arg == 2 * r ? gv : 0.f;                                                       \
+              z1 += arg == 2 * r + 1 ? gv : 0.f;                                                   \
+              const unsigned off = okw ? (unsigned)(((nn * 64 + ch) * p.H + y + r) * p.W + 2 * xp) * 4u : 0x80000000u; \
+              __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(unsigned, z0), __builtin_bit_cast(unsigned, z1)}, prs, off, 0, 0); \
+            }                                                                                      \
+          }                                                                                        \
+  } else {                                                                                         \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n) ps_keep(ACC[m][n]);                            \
+  }
   // the whole epilogue of ACC (geometry in ob / okn) at once: every load precedes the first store
 #define PS_EPILOGUE(ACC)                                                                           \
-  if (!(PS_DBG & 1)) {                                                                             \
+  if constexpr (MODE == PSE_FWD_POOL) { PS_EPI_FWD_POOL(ACC, tile) }                               \
+  else if constexpr (MODE == PSE_DGRAD_ADDPOOL) { PS_EPI_ADDPOOL(ACC, tile) }                      \
+  else if (!(PS_DBG & 1)) {                                                                        \
     u32x2_t sg[MODE == PSE_DGRAD_ACT ? 4 : 1][2][2][4];                                            \
     if (MODE == PSE_DGRAD_ACT) {                                                                   \
       /* the saved activation: this lane's 4 channels (8 bytes) of groups 4m+2gp and 4m+2gp+1, hi and lo */ \
@@ -332,7 +487,7 @@ k_conv3x3_ps(const PsConvArgs p) {
     PS_GEO(tile)                                                                                   \
     if (!WOVEN) {                                                                                  \
       PS_EPILOGUE(ACC)                                                                             \
-      young = (PS_DBG & 1) ? 0 : 32;                                                               \
+      young = (PS_DBG & 1) ? 0 : (POOLM ? pool_cnt : 32);                                          \
     }                                                                                              \
   }
 
@@ -352,6 +507,10 @@ k_conv3x3_ps(const PsConvArgs p) {
   }
 #undef PS_TILE
 #undef PS_EPILOGUE
+#undef PS_EPI_ADDPOOL
+#undef PS_EPI_FWD_POOL
+#undef PS_WIN
+#undef PS_WAITN
 #undef PS_BODY
 #undef PS_FRAGS
 #undef PS_NEXT
@@ -385,10 +544,16 @@ int launch_ps(const PsConvArgs& p, size_t lds, int grid, hipStream_t st) {
   return check_launch("fdet_conv3x3_ps");
 }
 
-int run_ps(int mode, const void* x, const void* wpk, const float* bias, const void* aux, void* y, int N, int Cin, int Cout,
-           int H, int W, float slope, hipStream_t st) {
-  PsGeo gi, go;
-  FDET_REQUIRE(x && wpk && y, "conv3x3_ps: null pointer");
+struct PsPoolIO {
+  const float* scale = nullptr; void* pool_ps = nullptr; float* pool_f32 = nullptr; unsigned char* route_out = nullptr;
+  const float* dout = nullptr; const unsigned char* route_in = nullptr; float* dx_f32 = nullptr;
+};
+
+int run_ps(int mode, const void* x, const void* wpk, const float* bias, const void* aux, void* y, const PsPoolIO& io, int N,
+           int Cin, int Cout, int H, int W, float slope, hipStream_t st) {
+  PsGeo gi, go, gp;
+  const bool pooled = mode == PSE_FWD_POOL || mode == PSE_DGRAD_ADDPOOL;
+  FDET_REQUIRE(x && wpk && (y || pooled), "conv3x3_ps: null pointer");
   FDET_REQUIRE(Cout == 64 && Cin % 16 == 0 && Cin >= 32, "conv3x3_ps: Cout must be 64 and Cin a multiple of 16 (Cin=%d Cout=%d)", Cin, Cout);
   FDET_REQUIRE(ps_geo(N, Cin, H, W, gi) && ps_geo(N, Cout, H, W, go) && gi.WP >= 32, "conv3x3_ps: unsupported map %dx%d", H, W);
   FDET_REQUIRE(slope >= 0.f && slope <= 1.f, "conv3x3_ps: slope must be in [0, 1]");
@@ -400,6 +565,17 @@ int run_ps(int mode, const void* x, const void* wpk, const float* bias, const vo
   p.bias = bias;
   p.y = reinterpret_cast<bf16x8*>(y);
   p.aux = reinterpret_cast<const bf16x8*>(aux);
+  p.scale = io.scale; p.pool_ps = reinterpret_cast<bf16x8*>(io.pool_ps); p.pool_f32 = io.pool_f32; p.route_out = io.route_out;
+  p.dout = io.dout; p.route_in = io.route_in; p.dx_f32 = io.dx_f32;
+  p.Hp = H / 2; p.Wp = W / 2; p.HPp = p.WPp = p.plane_p = p.img_p = 0;
+  if (pooled) {
+    FDET_REQUIRE(!(H & 1) && !(W & 1) && Cin == 64, "conv3x3_ps (pooled block): even map and 64 channels required (H=%d W=%d Cin=%d)", H, W, Cin);
+    FDET_REQUIRE((size_t)N * 64 * H * W * 4 < ((size_t)1 << 31), "conv3x3_ps (pooled block): tensor too large for 32-bit offsets");
+    if (mode == PSE_FWD_POOL && io.pool_ps) {
+      FDET_REQUIRE(ps_geo(N, 64, H / 2, W / 2, gp), "conv3x3_ps_fwd_pool: the pooled map %dx%d has no PS layout", H / 2, W / 2);
+      p.HPp = gp.HP; p.WPp = gp.WP; p.plane_p = gp.plane; p.img_p = gp.img;
+    }
+  }
   p.N = N; p.H = H; p.W = W; p.HP = gi.HP;
   p.nch = Cin / 16;
   const int R = 512 / gi.WP, PT = (R + 2) * gi.WP + 8;
@@ -411,12 +587,21 @@ int run_ps(int mode, const void* x, const void* wpk, const float* bias, const vo
   p.slope = slope;
   const size_t lds = (size_t)2 * (2 * PSA + 4 * PT) * 16;
   const int grid = std::min(p.ntiles, ps_num_cus());
-  if (mode == PSE_FWD_FULL) {
-    FDET_REQUIRE(bias, "conv3x3_ps_fwd: bias is required");
-    return gi.WP == 64 ? launch_ps<PSE_FWD_FULL, 64>(p, lds, grid, st) : launch_ps<PSE_FWD_FULL, 32>(p, lds, grid, st);
+  const bool w64 = gi.WP == 64;
+  switch (mode) {
+    case PSE_FWD_FULL:
+      FDET_REQUIRE(bias, "conv3x3_ps_fwd: bias is required");
+      return w64 ? launch_ps<PSE_FWD_FULL, 64>(p, lds, grid, st) : launch_ps<PSE_FWD_FULL, 32>(p, lds, grid, st);
+    case PSE_DGRAD_ACT:
+      FDET_REQUIRE(aux, "conv3x3_ps_dgrad_act: the activation is required");
+      return w64 ? launch_ps<PSE_DGRAD_ACT, 64>(p, lds, grid, st) : launch_ps<PSE_DGRAD_ACT, 32>(p, lds, grid, st);
+    case PSE_FWD_POOL:
+      FDET_REQUIRE(bias && aux && (io.pool_ps || io.pool_f32), "conv3x3_ps_fwd_pool: bias, skip and an output are required");
+      return w64 ? launch_ps<PSE_FWD_POOL, 64>(p, lds, grid, st) : launch_ps<PSE_FWD_POOL, 32>(p, lds, grid, st);
+    default:
+      FDET_REQUIRE(io.dout && io.route_in && io.dx_f32, "conv3x3_ps_dgrad_unpool: dout, route and dx are required");
+      return w64 ? launch_ps<PSE_DGRAD_ADDPOOL, 64>(p, lds, grid, st) : launch_ps<PSE_DGRAD_ADDPOOL, 32>(p, lds, grid, st);
   }
-  FDET_REQUIRE(aux, "conv3x3_ps_dgrad: the activation is required");
-  return gi.WP == 64 ? launch_ps<PSE_DGRAD_ACT, 64>(p, lds, grid, st) : launch_ps<PSE_DGRAD_ACT, 32>(p, lds, grid, st);
 }
 
 }  // namespace
@@ -425,11 +610,33 @@ int run_ps(int mode, const void* x, const void* wpk, const float* bias, const vo
 // fdet_pack_conv3x3_weights_bf16x3
 extern "C" int fdet_conv3x3_ps_fwd(const void* x_ps, const void* wpk, const float* bias, void* y_ps, int N, int Cin,
                                    int Cout, int H, int W, float slope, void* stream) {
-  return run_ps(PSE_FWD_FULL, x_ps, wpk, bias, nullptr, y_ps, N, Cin, Cout, H, W, slope, (hipStream_t)stream);
+  return run_ps(PSE_FWD_FULL, x_ps, wpk, bias, nullptr, y_ps, PsPoolIO{}, N, Cin, Cout, H, W, slope, (hipStream_t)stream);
 }
 
 // dx_ps = conv3x3^T(dz_ps, W) * LeakyReLU'(act_ps); wpk: backward panels
 extern "C" int fdet_conv3x3_ps_dgrad_act(const void* dz_ps, const void* wpk, const void* act_ps, void* dx_ps, int N,
                                          int Cin, int Cout, int H, int W, float slope, void* stream) {
-  return run_ps(PSE_DGRAD_ACT, dz_ps, wpk, nullptr, act_ps, dx_ps, N, Cout, Cin, H, W, slope, (hipStream_t)stream);
+  return run_ps(PSE_DGRAD_ACT, dz_ps, wpk, nullptr, act_ps, dx_ps, PsPoolIO{}, N, Cout, Cin, H, W, slope, (hipStream_t)stream);
+}
+
+// Pooled residual block on PS tensors (models/PoolResnet.py:36-42 and its autograd), the tail fused as in
+// fdet_conv3x3_fwd_pool_bf16x3 / fdet_conv3x3_dgrad_unpool_bf16x3:
+//   forward : pooled = maxpool2x2(LeakyReLU(conv(x_ps) + bias) * drop_scale + skip_ps) -> pool_ps (PS) and / or pool_f32
+//             (fp32 NCHW); route8 [N][8][H/2][W/2][8] bytes (channel-innermost; NULL in eval): bits 0-3 = (c > 0) of the
+//             window's elements in scan order, bits 4-5 = index of the maximum (first maximum wins, NaN is a maximum)
+//   backward: dx (fp32 NCHW) = conv^T(dz_ps) + unpool(dout_pooled) through route8
+extern "C" int fdet_conv3x3_ps_fwd_pool(const void* x_ps, const void* wpk, const float* bias, const void* skip_ps,
+                                        const float* drop_scale, void* pool_ps, float* pool_f32, unsigned char* route8,
+                                        int N, int Cin, int Cout, int H, int W, float slope, void* stream) {
+  PsPoolIO io;
+  io.scale = drop_scale; io.pool_ps = pool_ps; io.pool_f32 = pool_f32; io.route_out = route8;
+  return run_ps(PSE_FWD_POOL, x_ps, wpk, bias, skip_ps, nullptr, io, N, Cin, Cout, H, W, slope, (hipStream_t)stream);
+}
+
+extern "C" int fdet_conv3x3_ps_dgrad_unpool(const void* dz_ps, const void* wpk, const float* dout_pooled,
+                                            const unsigned char* route8, float* dx, int N, int Cin, int Cout, int H, int W,
+                                            float slope, void* stream) {
+  PsPoolIO io;
+  io.dout = dout_pooled; io.route_in = route8; io.dx_f32 = dx;
+  return run_ps(PSE_DGRAD_ADDPOOL, dz_ps, wpk, nullptr, nullptr, nullptr, io, N, Cout, Cin, H, W, slope, (hipStream_t)stream);
 }

@@ -44,7 +44,57 @@ k_ps_to_f32(const ps_bf16x8* __restrict__ ps, float* __restrict__ x, PsGeo g, in
   for (int j = 0; j < 8; ++j) dst[j * HW] = (float)hi[j] + (float)lo[j];
 }
 
+// backward of the fused pooled-block tail into a PS tensor: dz2 = unpool(dout) * drop_scale * lrelu'(c) from the pooled
+// gradient (fp32 NCHW) and the channel-innermost routing bytes (route8 [N][C/8][Hp][Wp][8]) of the forward pass.
+// One thread per (image, channel group, window): 8 channels x 4 positions = four hi and four lo units.
+__global__ void __launch_bounds__(256)
+k_pool_route_bwd_ps(const float* __restrict__ dout, const unsigned char* __restrict__ route8, const float* __restrict__ scale,
+                    ps_bf16x8* __restrict__ dz, PsGeo g, int Hp, int Wp, float slope, int total) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int xp = t % Wp, r = t / Wp;
+  const int yp = r % Hp, r2 = r / Hp;
+  const int gr = r2 % g.C8, n = r2 / g.C8;
+  const size_t HWp = (size_t)Hp * Wp;
+  const float* src = dout + ((size_t)n * g.C + gr * 8) * HWp + (size_t)yp * Wp + xp;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 rb = *reinterpret_cast<const u32x2*>(route8 + (((size_t)(n * g.C8 + gr) * Hp + yp) * Wp + xp) * 8);
+  float gv[8];
+  unsigned mk[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    gv[j] = src[j * HWp] * (scale ? scale[n * g.C + gr * 8 + j] : 1.f);
+    mk[j] = (rb[j >> 2] >> (8 * (j & 3))) & 0xffu;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ps_bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = ((int)((mk[j] >> 4) & 3) == k) ? gv[j] * (((mk[j] >> k) & 1) ? 1.f : slope) : 0.f;
+      const __bf16 h = (__bf16)f;
+      hi[j] = h;
+      lo[j] = (__bf16)(f - (float)h);
+    }
+    const size_t u = (size_t)n * g.img + (size_t)(gr * g.HP + 2 * yp + (k >> 1)) * g.WP + 2 * xp + (k & 1) + 1;
+    dz[u] = hi;
+    dz[u + g.plane] = lo;
+  }
+}
+
 }  // namespace
+
+extern "C" int fdet_pool_route_bwd_ps(const float* dout_pooled, const unsigned char* route8, const float* drop_scale,
+                                      void* dz2_ps, int N, int C, int H, int W, float slope, void* stream) {
+  PsGeo g;
+  FDET_REQUIRE(dout_pooled && route8 && dz2_ps && !(H & 1) && !(W & 1) && ps_geo(N, C, H, W, g),
+               "pool_route_bwd_ps: unsupported shape N=%d C=%d H=%d W=%d (even H, W; C %% 8 == 0; W <= 62)", N, C, H, W);
+  const long long total = (long long)N * g.C8 * (H / 2) * (W / 2);
+  FDET_REQUIRE(total < (1ll << 31), "pool_route_bwd_ps: tensor too large");
+  hipLaunchKernelGGL(k_pool_route_bwd_ps, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     dout_pooled, route8, drop_scale, reinterpret_cast<ps_bf16x8*>(dz2_ps), g, H / 2, W / 2, slope, (int)total);
+  return check_launch("fdet_pool_route_bwd_ps");
+}
 
 extern "C" size_t fdet_ps_bytes(int N, int C, int H, int W) {
   PsGeo g;

@@ -102,3 +102,53 @@ def conv3x3_wgrad_ps_batched(xs, dzs, dWs, dbs, ws: torch.Tensor) -> None:
     check(lib().fdet_conv3x3_wgrad_ps_batched(arr(*[x.data for x in xs]), arr(*[z.data for z in dzs]),
                                               arr(*[ptr(t) for t in dWs]), arr(*[ptr(t) for t in dbs]), L, N, C, H, W,
                                               ptr(ws), ws.numel() * 4, stream()), "fdet_conv3x3_wgrad_ps_batched")
+
+
+def route8_like(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
+    """Routing bytes of a pooled block whose conv maps are (H, W): uint8 [N, C/8, H/2, W/2, 8]."""
+    return torch.empty(N, C // 8, H // 2, W // 2, 8, dtype=torch.uint8, device=device)
+
+
+def conv3x3_ps_fwd_pool(x: PsTensor, wpk, bias, skip: PsTensor, drop_scale, pool_ps: PsTensor = None,
+                        pool_f32: torch.Tensor = None, route8: torch.Tensor = None, slope: float = 0.2) -> None:
+    """pooled = maxpool2x2(lrelu(conv(x)+bias) * drop_scale + skip) -> pool_ps and / or pool_f32; route8: routing bytes."""
+    N, cin, H, W = x.shape
+    cout = int(bias.shape[0])
+    _same(skip, (N, cout, H, W), "conv3x3_ps_fwd_pool: skip")
+    if pool_ps is not None:
+        _same(pool_ps, (N, cout, H // 2, W // 2), "conv3x3_ps_fwd_pool: pool_ps")
+    if pool_f32 is not None and tuple(pool_f32.shape) != (N, cout, H // 2, W // 2):
+        raise ValueError("conv3x3_ps_fwd_pool: pool_f32 shape")
+    if route8 is not None and tuple(route8.shape) != (N, cout // 8, H // 2, W // 2, 8):
+        raise ValueError("conv3x3_ps_fwd_pool: route8 shape")
+    if drop_scale is not None and tuple(drop_scale.shape) != (N, cout):
+        raise ValueError("conv3x3_ps_fwd_pool: drop_scale shape")
+    if wpk.numel() != cout * cin * 9:
+        raise ValueError("conv3x3_ps_fwd_pool: packed weight size does not match (Cout,Cin)")
+    check(lib().fdet_conv3x3_ps_fwd_pool(x.data, ptr(wpk), ptr(bias), skip.data, ptr(drop_scale),
+                                         pool_ps.data if pool_ps is not None else None, ptr(pool_f32),
+                                         ptr(route8, torch.uint8), N, cin, cout, H, W, float(slope), stream()),
+          "fdet_conv3x3_ps_fwd_pool")
+
+
+def pool_route_bwd_ps(dout_pooled: torch.Tensor, route8: torch.Tensor, drop_scale, dz2: PsTensor, slope: float = 0.2) -> None:
+    """dz2 (PS) = unpool(dout_pooled) * drop_scale * lrelu'(c) from the routing bytes."""
+    N, C, H, W = dz2.shape
+    if tuple(dout_pooled.shape) != (N, C, H // 2, W // 2) or tuple(route8.shape) != (N, C // 8, H // 2, W // 2, 8):
+        raise ValueError("pool_route_bwd_ps: shapes")
+    check(lib().fdet_pool_route_bwd_ps(ptr(dout_pooled), ptr(route8, torch.uint8), ptr(drop_scale), dz2.data, N, C, H, W,
+                                       float(slope), stream()), "fdet_pool_route_bwd_ps")
+
+
+def conv3x3_ps_dgrad_unpool(dz: PsTensor, wpk_bwd, dout_pooled: torch.Tensor, route8: torch.Tensor, dx: torch.Tensor,
+                            slope: float = 0.2) -> None:
+    """dx (fp32 NCHW) = conv3x3^T(dz) + unpool(dout_pooled) through the routing bytes."""
+    N, cout, H, W = dz.shape
+    cin = dx.shape[1]
+    if tuple(dx.shape) != (N, cin, H, W) or tuple(dout_pooled.shape) != (N, cin, H // 2, W // 2) or \
+            tuple(route8.shape) != (N, cin // 8, H // 2, W // 2, 8):
+        raise ValueError("conv3x3_ps_dgrad_unpool: shapes")
+    if wpk_bwd.numel() != cout * cin * 9:
+        raise ValueError("conv3x3_ps_dgrad_unpool: packed weight size does not match (Cout,Cin)")
+    check(lib().fdet_conv3x3_ps_dgrad_unpool(dz.data, ptr(wpk_bwd), ptr(dout_pooled), ptr(route8, torch.uint8), ptr(dx),
+                                             N, cin, cout, H, W, float(slope), stream()), "fdet_conv3x3_ps_dgrad_unpool")

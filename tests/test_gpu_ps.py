@@ -102,3 +102,74 @@ def test_conv3x3_wgrad_ps(env, shape, L):
     dW2 = [torch.empty_like(t) for t in dW]; db2 = [torch.empty_like(t) for t in db]
     ps.conv3x3_wgrad_ps_batched(xp, zp, dW2, db2, ws)
     assert all(torch.equal(a, b) for a, b in zip(dW + db, dW2 + db2))
+
+
+def _route_to_nchw(route8):
+    N, G, Hp, Wp, _ = route8.shape
+    return route8.permute(0, 1, 4, 2, 3).reshape(N, G * 8, Hp, Wp)
+
+
+POOL_SHAPES = [(3, 64, 60, 60), (5, 64, 30, 30), (2, 64, 12, 56), (9, 64, 16, 30)]
+
+
+@pytest.mark.parametrize("shape", POOL_SHAPES)
+@pytest.mark.parametrize("train", [True, False])
+def test_conv3x3_ps_pooled_block(env, shape, train):
+    """Forward tail fused into conv2 and both backward pieces against torch ops on the CPU; routing bytes checked
+    wherever the reference leaves no doubt (sign of c away from zero, a unique window maximum)."""
+    hp, ps = env
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(N * 31 + H + W + int(train))
+    x = torch.randn(N, C, H, W, generator=g)
+    skip = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    scale = (torch.rand(N, C, generator=g) > 0.25).float() / 0.75 if train else None
+    nf, nb = hp.packed_sizes(C, C)
+    wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda")
+    hp.pack_conv3x3_weights(w.cuda(), wf, wb, x3=True)
+    xp = ps.PsTensor.from_f32(x.cuda()); sp = ps.PsTensor.from_f32(skip.cuda())
+    pool_ps = ps.PsTensor(N, C, H // 2, W // 2, "cuda")
+    pool_f = torch.full((N, C, H // 2, W // 2), float("nan"), device="cuda")
+    route = ps.route8_like(N, C, H, W, "cuda") if train else None
+    ps.conv3x3_ps_fwd_pool(xp, wf, b.cuda(), sp, scale.cuda() if train else None, pool_ps, pool_f, route)
+    xr, sr = xp.to_f32().cpu(), sp.to_f32().cpu()
+    c = F.leaky_relu(F.conv2d(xr, w, b, padding=1), 0.2)
+    u = c * (scale[:, :, None, None] if train else 1.0) + sr
+    ref, idx = F.max_pool2d(u, 2, return_indices=True)
+    close(pool_f, ref)
+    close(pool_ps.to_f32(), ref)
+    if not train:
+        return
+    rt = _route_to_nchw(route).cpu().int()
+    # argmax: windows whose best two values differ clearly
+    win = F.unfold(u.reshape(N * C, 1, H, W), 2, stride=2).reshape(N, C, 4, H // 2, W // 2)   # scan order (r0c0, r0c1, r1c0, r1c1)
+    top2 = win.topk(2, dim=2).values
+    clear = (top2[:, :, 0] - top2[:, :, 1]) > 1e-3
+    assert torch.equal(((rt >> 4) & 3)[clear], win.argmax(dim=2).int()[clear])
+    cw = F.unfold(c.reshape(N * C, 1, H, W), 2, stride=2).reshape(N, C, 4, H // 2, W // 2)
+    for k in range(4):
+        sure = cw[:, :, k].abs() > 1e-3
+        assert torch.equal(((rt >> k) & 1)[sure], (cw[:, :, k] > 0).int()[sure])
+    # backward of the tail from the routing bytes: dz2 = unpool(dout) * scale * lrelu'(c)
+    dout = torch.randn(N, C, H // 2, W // 2, generator=g)
+    dz2 = ps.PsTensor(N, C, H, W, "cuda")
+    ps.pool_route_bwd_ps(dout.cuda(), route, scale.cuda(), dz2)
+    arg = (rt >> 4) & 3
+    ref_dz = torch.zeros(N, C, 4, H // 2, W // 2)
+    gs = dout * scale[:, :, None, None]
+    for k in range(4):
+        ref_dz[:, :, k] = torch.where(arg == k, gs * torch.where(((rt >> k) & 1) == 1, 1.0, 0.2), torch.zeros(()))
+    ref_dz = F.fold(ref_dz.reshape(N * C, 4, -1), (H, W), 2, stride=2).reshape(N, C, H, W)
+    got = dz2.to_f32().cpu()
+    assert torch.all((got - ref_dz).abs() <= ref_dz.abs() * 2.0 ** -15)
+    # conv1's data gradient + the un-pooled skip gradient
+    dz1 = torch.randn(N, C, H, W, generator=g)
+    dzp = ps.PsTensor.from_f32(dz1.cuda())
+    dx = torch.full((N, C, H, W), float("nan"), device="cuda")
+    ps.conv3x3_ps_dgrad_unpool(dzp, wb, dout.cuda(), route, dx)
+    un = torch.zeros(N, C, 4, H // 2, W // 2)
+    for k in range(4):
+        un[:, :, k] = torch.where(arg == k, dout, torch.zeros(()))
+    un = F.fold(un.reshape(N * C, 4, -1), (H, W), 2, stride=2).reshape(N, C, H, W)
+    close(dx, F.conv_transpose2d(dzp.to_f32().cpu(), w, padding=1) + un)
