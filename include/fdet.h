@@ -327,6 +327,10 @@ int fdet_pool_route_bwd_ps(const float* dout_pooled, const unsigned char* route8
                            int N, int C, int H, int W, float slope, void* stream);
 int fdet_conv3x3_ps_dgrad_unpool(const void* dz_ps, const void* wpk, const float* dout_pooled, const unsigned char* route8,
                                  float* dx, int N, int Cin, int Cout, int H, int W, float slope, void* stream);
+/* The PoolResnet stem Conv2d(3,64,10,s8,p2)+bias (models/PoolResnet.py:70-72) writing its output as a PS tensor
+ * (image-0 pointer of an (N,64,Ho,Wo) PS allocation): same arithmetic as fdet_stem_fwd_bf16x3. */
+int fdet_stem_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int Cin, int F, int H, int W,
+                     int k, int stride, int pad, void* stream);
 /* Weight / bias gradients of L same-shape 64-channel 3x3 layers from PS tensors (h_x[l], h_dz[l]: host arrays of
  * image-0 device pointers): dW[l] [64,64,3,3], db[l] [64] (autograd of models/PoolResnet.py:33-36; same results as
  * fdet_conv3x3_wgrad_bf16x3_batched to the rounding of the PS format).  ws: fdet_conv3x3_wgrad_ps_ws_bytes bytes

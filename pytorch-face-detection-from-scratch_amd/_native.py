@@ -81,6 +81,7 @@ SIGNATURES = {
     "fdet_conv3x3_ps_fwd_pool": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_pool_route_bwd_ps": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_ps_dgrad_unpool": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_stem_fwd_ps": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_conv3x3_wgrad_ps_ws_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "fdet_conv3x3_wgrad_ps_batched": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "fdet_pointwise_packed_bytes": (_SZ, [_I, _I]),

@@ -18,6 +18,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import hotpath as hp
+from . import ps as psm
 
 F32 = torch.float32
 
@@ -109,6 +110,23 @@ class _NoSpan:
 _NOSPAN = _NoSpan()
 
 
+class _PsScope(list):
+    """PS buffers leased by one forward pass: [(pool key, PsTensor)]; they go back to the engine's pool when the scope
+    is released explicitly or dropped (CPython: as soon as the saved state of the pass is)."""
+
+    def __init__(self, pool):
+        super().__init__()
+        self.pool = pool
+
+    def release(self):
+        for key, t in self:
+            self.pool.setdefault(key, []).append(t)
+        self.clear()
+
+    def __del__(self):
+        self.release()
+
+
 class ConvStack:
     """Owns packed weights, workspaces and saved activations; parameters are passed in as a
     dict of GPU tensors named like the reference's state_dict."""
@@ -138,6 +156,10 @@ class ConvStack:
         # rocprofv3 --stats) meaningless, so the default keeps one stream
         self.wgrad_stream = os.environ.get("FDET_WGRAD_STREAM", "0") == "1"
         self._side = None
+        # pre-split (PS) activations for the pooled 64-channel blocks (ps.py, csrc/fdet_ps.h): stem output, conv outputs
+        # and their gradients live as bf16 hi|lo units, staged by LDS-DMA (FDET_PS=0: the fp32-I/O kernels of round 2)
+        self.ps = self.pool_fusion and geo.filters == 64 and os.environ.get("FDET_PS", "1") != "0"
+        self._ps_pool: Dict[tuple, list] = {}
 
     def _t(self, kind: str, N: int, h: int, flops: float = 0.0, nbytes: float = 0.0):
         if self.timer is None:
@@ -189,6 +211,24 @@ class ConvStack:
     def _fused_pool(self, hk: int) -> bool:
         return self.pool_fusion and hp.pool_fusion_supported(self.geo.filters, self.geo.filters, hk, hk)
 
+    # ------------------------------------------------------------------ PS buffers
+    def _ps_block(self, k: int) -> bool:
+        """Block k runs on pre-split activations: a pooled block whose even map is 30..62 columns wide."""
+        if not self.ps or k >= len(self.lv):
+            return False
+        hk, pool = self.lv[k]
+        return pool == 2 and hk % 2 == 0 and 30 <= hk <= 62 and self._fused_pool(hk)
+
+    def _ps_take(self, scope: "_PsScope", N: int, C: int, H: int, W: int, dev) -> "psm.PsTensor":
+        """A zero-haloed PS buffer from the engine's pool; it returns to the pool when `scope` (kept alive by the saved
+        state of a forward pass, or released at the end of an inference call) goes away.  Producers write real elements
+        only, so a recycled buffer still has zero halos."""
+        key = (N, C, H, W, str(dev))
+        free = self._ps_pool.setdefault(key, [])
+        t = free.pop() if free else psm.PsTensor(N, C, H, W, dev)
+        scope.append((key, t))
+        return t
+
     def _chain_run(self, k: int) -> int:
         """Number of consecutive un-pooled blocks starting at block k that can run as one
         LDS-resident chain (bf16x3, 64 channels, small maps); 0/1 = use the per-layer kernels."""
@@ -217,17 +257,44 @@ class ConvStack:
         self._ensure_packed(P)
         N, F_, dev = x.shape[0], g.filters, x.device
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
-        h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev)
+        h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev) if not (self._ps_block(0) and self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)) else None
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
         stem_bytes = 4.0 * N * (g.in_ch * g.H * g.W + F_ * self.h0 * self.h0)
+        scope = _PsScope(self._ps_pool)
+        h_ps = None
+        stem_x3 = self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)
         with self._t("stem_fwd", N, self.h0, stem_flops, stem_bytes):
-            hp.stem_fwd(x, P["conv1.weight"], P["conv1.bias"], h, ws, g.stem_k, g.stem_s, g.stem_p,
-                        x3=self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p))
-        saved = {"x": x, "blocks": [], "masks": masks} if save else None
+            if self._ps_block(0) and stem_x3:
+                h, h_ps = None, self._ps_take(scope, N, F_, self.h0, self.h0, dev)
+                psm.stem_fwd_ps(x, P["conv1.weight"], P["conv1.bias"], h_ps, g.stem_k, g.stem_s, g.stem_p)
+            else:
+                hp.stem_fwd(x, P["conv1.weight"], P["conv1.bias"], h, ws, g.stem_k, g.stem_s, g.stem_p, x3=stem_x3)
+        saved = {"x": x, "blocks": [], "masks": masks, "ps_scope": scope} if save else None
         k = -1
         while k + 1 < len(self.lv):
             k += 1
             hk, pool = self.lv[k]
+            if self._ps_block(k):
+                # pooled block on pre-split activations: conv1 -> a (PS); conv2 + tail -> pooled output (PS when the next
+                # block is a PS block too, else fp32 NCHW) + channel-innermost routing bytes
+                name = f"residual_blocks.{k}"
+                sc = masks[name] if masks is not None else None
+                if h_ps is None:
+                    h_ps = psm.PsTensor.from_f32(h, out=self._ps_take(scope, N, F_, hk, hk, dev))
+                a_ps = self._ps_take(scope, N, F_, hk, hk, dev)
+                with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2)):
+                    psm.conv3x3_ps_fwd(h_ps, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], a_ps, self.slope)
+                nxt = self._ps_block(k + 1)
+                out_ps = self._ps_take(scope, N, F_, hk // 2, hk // 2, dev) if nxt else None
+                out = None if nxt else torch.empty(N, F_, hk // 2, hk // 2, dtype=F32, device=dev)
+                route = psm.route8_like(N, F_, hk, hk, dev) if save else None
+                with self._t("conv3x3_fwd_pool", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2 + 0.25 + (1 / 16 if save else 0))):
+                    psm.conv3x3_ps_fwd_pool(a_ps, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], h_ps, sc, out_ps, out,
+                                            route, self.slope)
+                if save:
+                    saved["blocks"].append((h_ps, a_ps, route))
+                h, h_ps = out, out_ps
+                continue
             run = self._chain_run(k)
             if run > 1:
                 # blocks k .. k+run-1 keep their activation on the CU: one launch (fdet_block_chain_fwd_bf16x3)
@@ -278,6 +345,8 @@ class ConvStack:
         if save:
             saved["h_last"] = h
             saved["y"] = y
+        else:
+            scope.release()                                # inference: every PS buffer of the pass is free again
         return y, saved
 
     # ------------------------------------------------------------------ backward
@@ -333,6 +402,20 @@ class ConvStack:
                 side_keep.extend(pending)
             pending.clear()
 
+        pending_ps = []       # the same for blocks on pre-split activations: (x PS, dz PS, weight name)
+
+        def flush_ps(hk_):
+            if not pending_ps:
+                return
+            fl_ = self._conv_flops(N, hk_)
+            for i0 in range(0, len(pending_ps), 16):
+                grp = pending_ps[i0:i0 + 16]
+                wsb_ = self._workspace("wgrad_ps", psm.conv3x3_wgrad_ps_ws_bytes(len(grp), N, F_, hk_, hk_), dev)
+                with self._t("conv3x3_wgrad", N, hk_, fl_ * len(grp), self._act_bytes(N, hk_, 2) * len(grp)):
+                    psm.conv3x3_wgrad_ps_batched([p_[0] for p_ in grp], [p_[1] for p_ in grp],
+                                                 [G[p_[2] + ".weight"] for p_ in grp], [G[p_[2] + ".bias"] for p_ in grp], wsb_)
+            pending_ps.clear()
+
         # runs of blocks that went through the forward chain come back through the backward chain
         chain_start = {}
         kk = 0
@@ -376,6 +459,38 @@ class ConvStack:
             name = f"residual_blocks.{k}"
             xin, a, c = saved["blocks"][k]
             sc = masks[name] if masks is not None else None
+            if self._ps_block(k) and c is not None and c.dtype == torch.uint8 and \
+                    (isinstance(a, psm.PsTensor) or isinstance(xin, psm.PsTensor) or c.dim() == 5):
+                # pooled block on pre-split activations (a caller may have replaced saved tensors by fp32 / NCHW ones)
+                scope = saved.get("ps_scope")
+                if scope is None:
+                    scope = saved["ps_scope"] = _PsScope(self._ps_pool)
+                if not isinstance(xin, psm.PsTensor):
+                    xin = psm.PsTensor.from_f32(xin.to(F32).contiguous(), out=self._ps_take(scope, N, F_, hk, hk, dev))
+                if not isinstance(a, psm.PsTensor):
+                    a = psm.PsTensor.from_f32(a.to(F32).contiguous(), out=self._ps_take(scope, N, F_, hk, hk, dev))
+                if c.dim() == 4:                           # routing bytes in NCHW -> channel-innermost
+                    c = c.view(N, F_ // 8, 8, hk // 2, hk // 2).permute(0, 1, 3, 4, 2).contiguous()
+                fl = self._conv_flops(N, hk)
+                dz2 = self._ps_take(scope, N, F_, hk, hk, dev)
+                with self._t("pool_route_bwd", N, hk, 0.0, self._act_bytes(N, hk, 1 + 0.25 + 1 / 16)):
+                    psm.pool_route_bwd_ps(dout, c, sc, dz2, self.slope)
+                dz1 = self._ps_take(scope, N, F_, hk, hk, dev)
+                with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
+                    psm.conv3x3_ps_dgrad_act(dz2, self._wpk[name + ".conv2.b"], a, dz1, self.slope)
+                dx = torch.empty(N, F_, hk, hk, dtype=F32, device=dev)
+                with self._t("conv3x3_dgrad_unpool", N, hk, fl, self._act_bytes(N, hk, 2 + 0.25 + 1 / 16)):
+                    psm.conv3x3_ps_dgrad_unpool(dz1, self._wpk[name + ".conv1.b"], dout, c, dx, self.slope)
+                pending_ps.append((a, dz2, name + ".conv2"))
+                pending_ps.append((xin, dz1, name + ".conv1"))
+                dout = dx
+                if k == 0 or self.lv[k - 1][0] != hk or not self._ps_block(k - 1):
+                    flush_ps(hk)
+                    if after_block is not None:
+                        for kk in range(k, g.num_blocks):
+                            if self.lv[kk][0] == hk:
+                                after_block(kk)
+                continue
             dz2 = torch.empty_like(a)
             fused_pool = pool == 2 and c.dtype == torch.uint8      # forward kept routing bytes instead of c
             de = torch.empty_like(a) if (pool == 2 and not fused_pool) else None
@@ -426,6 +541,9 @@ class ConvStack:
             hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p,
                           x3=self.x3 and g.W % 16 == 0 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p))
         join()
+        if saved.get("ps_scope") is not None:
+            saved["ps_scope"].release()                    # the saved PS activations / gradients are dead: back to the pool
+            saved["blocks"] = []
 
 
 def param_names(num_blocks: int) -> List[str]:

@@ -18,6 +18,7 @@ size_t stem_mfma_ws_floats(int N, int F, int H, int W);
 int stem_mfma_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W, hipStream_t st);
 int stem_mfma_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st);
 int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W, hipStream_t st);   // fdet_stem_x3.hip
+int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st);
 int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st);
 }
 
@@ -359,6 +360,16 @@ extern "C" int fdet_stem_fwd_bf16x3(const float* x, const float* w, const float*
                "stem_fwd_bf16x3: only the PoolResnet stem (3ch k10 s8 p2, W%%4==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
                Cin, k, stride, pad, W);
   return stem_x3_fwd(x, w, bias, y, N, F, H, W, (hipStream_t)stream);
+}
+
+// the PoolResnet stem with a pre-split (PS) output: y_ps = image-0 pointer of a PS tensor (N, 64, Ho, Wo)
+extern "C" int fdet_stem_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int Cin, int F, int H,
+                                int W, int k, int stride, int pad, void* stream) {
+  FDET_REQUIRE(x && w && bias && y_ps && N > 0 && F == 64, "stem_fwd_ps: bad arguments (F must be 64)");
+  FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad),
+               "stem_fwd_ps: only the PoolResnet stem (3ch k10 s8 p2, W%%4==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
+               Cin, k, stride, pad, W);
+  return stem_x3_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream);
 }
 
 extern "C" int fdet_stem_wgrad_bf16x3(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,

@@ -9,6 +9,7 @@
 // stride-8 of the conv turns into the natural 8-element fragment granularity).
 // Weights live in registers for the whole kernel (30 rows x (hi,lo) x 4 VGPRs = 240 per lane).
 #include "fdet_common.h"
+#include "fdet_ps.h"
 #include <cstdlib>
 #include <utility>
 
@@ -29,6 +30,8 @@ constexpr int NSLOT = 15;                  // float4 staging slots per thread: 3
 struct StemX3Args {
   const float* x; const float* w; const float* bias; float* y;
   int N, F, H, W, Ho, Wo, nrows;
+  // PS output (fdet_ps.h) of the pipelined kernel: y is then the image-0 pointer of a PS tensor (F == 64)
+  int ps_hp, ps_wp, ps_plane, ps_img;
 };
 
 __global__ void __launch_bounds__(256, 1)
@@ -172,8 +175,10 @@ __device__ __forceinline__ void sx_split_pair(float f0, float f1, unsigned& hi, 
   lo = __builtin_bit_cast(unsigned, lb);
 }
 
+template <bool PSO>
 __global__ void __launch_bounds__(256, 1)
 k_stem_fwd_x3_pipe(const StemX3Args a) {
+  constexpr int NST = PSO ? 4 : 16;                    // output stores per row (they sit in the memory queue of the counted waits)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = NROW * RL * 2;                   // bf16 elements per tile: hi rows, then lo rows
   __bf16* const base = reinterpret_cast<__bf16*>(smem);
@@ -266,7 +271,7 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
     _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                \
     bf16x8 bh[2], bl[2];                                                                        \
     bh[0] = Bh[0]; bl[0] = Bl[0];                                                               \
-    SXP_WAIT(S, 16 + NSLOT)                                                                     \
+    SXP_WAIT(S, NST + NSLOT)                                                                    \
     sx_static_for<NROW>(SX_LAMBDA(rr_) {                                                        \
       constexpr int rr = rr_;                                                                   \
       constexpr int cur = rr & 1, nxt = cur ^ 1;                                                \
@@ -278,16 +283,42 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
       if constexpr (rr >= 4 && rr - 4 < NSLOT) SXP_LOAD1(S, rr - 4, n3_, oy3_)                  \
       __builtin_amdgcn_sched_barrier(0);                                                        \
     });                                                                                         \
+    if constexpr (PSO) {                                                                        \
+      /* PS output: lane = position, registers = channels 32m + 8g + 4half + i; a v_permlane32_swap pair leaves a */ \
+      /* lane with the 8 channels of one unit (as fdet_conv3x3_ps.hip): two 16-byte stores per group pair          */ \
+      _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                        \
+        float za[4], zb[4];                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
+          za[i] = acc[8 * gp + i] + sbias[m * 32 + 16 * gp + 4 * half + i];                     \
+          zb[i] = acc[8 * gp + 4 + i] + sbias[m * 32 + 16 * gp + 8 + 4 * half + i];             \
+        }                                                                                       \
+        unsigned ha[2], la[2], hb[2], lb[2];                                                    \
+        ps_split4(za, ha, la);                                                                  \
+        ps_split4(zb, hb, lb);                                                                  \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                         \
+          auto r1 = __builtin_amdgcn_permlane32_swap(ha[k], hb[k], false, false);               \
+          ha[k] = r1[0]; hb[k] = r1[1];                                                         \
+          auto r2 = __builtin_amdgcn_permlane32_swap(la[k], lb[k], false, false);               \
+          la[k] = r2[0]; lb[k] = r2[1];                                                         \
+        }                                                                                       \
+        const int G = 4 * m + 2 * gp + half;                                                    \
+        const unsigned off = ox < a.Wo ? (unsigned)(n * a.ps_img + (G * a.ps_hp + oy) * a.ps_wp + ox + 1) * 16u : 0x80000000u; \
+        typedef unsigned sx_u32x4 __attribute__((ext_vector_type(4)));                          \
+        __builtin_amdgcn_raw_buffer_store_b128(sx_u32x4{ha[0], ha[1], hb[0], hb[1]}, ry, off, 0, 0); \
+        __builtin_amdgcn_raw_buffer_store_b128(sx_u32x4{la[0], la[1], lb[0], lb[1]}, ry, off, a.ps_plane * 16, 0); \
+      }                                                                                         \
+    } else {                                                                                    \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                            \
       const int c2 = cob * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;                     \
       const bool ok = ox < a.Wo && c2 < a.F;                                                    \
       const unsigned off = ok ? ((unsigned)((n * a.F + c2) * a.Ho + oy) * a.Wo + ox) * 4u : 0x80000000u; \
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[r] + sbias[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half]), ry, off, 0, 0); \
     }                                                                                           \
+    }                                                                                           \
     __syncthreads();                                                                            \
     row += 1;                                                                                   \
   }
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.N * a.F * a.Ho * a.Wo * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, PSO ? a.N * a.ps_img * 16 : a.N * a.F * a.Ho * a.Wo * 4, 0x00020000);
   while (row < last) {
     SXP_BAND(0, 1)
     if (row >= last) break;
@@ -740,13 +771,35 @@ int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int
   const char* e = getenv("FDET_STEM_PIPE");
   // pipelined kernel: 32-bit byte offsets into x and y (FDET_STEM_PIPE=0 keeps the single-tile kernel)
   if (!(e && e[0] == '0') && (size_t)N * CIN * H * W < ((size_t)1 << 29) && (size_t)N * F * a.Ho * a.Wo < ((size_t)1 << 29)) {
-    (void)hipFuncSetAttribute((const void*)k_stem_fwd_x3_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds + 256));
-    hipLaunchKernelGGL(k_stem_fwd_x3_pipe, dim3(nblk, FP / 64), dim3(256), 2 * lds + 256, st, a);
+    if (hipFuncSetAttribute((const void*)k_stem_fwd_x3_pipe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds + 256)) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(FDET_ELAUNCH, "stem_fwd(bf16x3): cannot reserve %zu bytes of LDS", 2 * lds + 256);
+    }
+    hipLaunchKernelGGL(k_stem_fwd_x3_pipe<false>, dim3(nblk, FP / 64), dim3(256), 2 * lds + 256, st, a);
     return check_launch("fdet_stem_fwd(bf16x3 pipelined)");
   }
   (void)hipFuncSetAttribute((const void*)k_stem_fwd_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_stem_fwd_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
   return check_launch("fdet_stem_fwd(bf16x3)");
+}
+
+// the same forward with a pre-split (PS) output: y_ps = image-0 pointer of a PS tensor (N, 64, Ho, Wo)
+int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st) {
+  StemX3Args a{};
+  a.x = x; a.w = w; a.bias = bias; a.y = reinterpret_cast<float*>(y_ps); a.N = N; a.F = F; a.H = H; a.W = W;
+  a.Ho = (H + 4 - 10) / 8 + 1; a.Wo = (W + 4 - 10) / 8 + 1; a.nrows = N * a.Ho;
+  PsGeo g;
+  if (F != 64 || !ps_geo(N, F, a.Ho, a.Wo, g) || (size_t)N * CIN * H * W >= ((size_t)1 << 29))
+    return fail(FDET_EINVAL, "stem_fwd_ps: unsupported shape (F=%d, output %dx%d)", F, a.Ho, a.Wo);
+  a.ps_hp = g.HP; a.ps_wp = g.WP; a.ps_plane = g.plane; a.ps_img = g.img;
+  const int nblk = a.nrows < 256 ? a.nrows : 256;
+  const size_t lds = (size_t)NROW * RL * 2 * 2;
+  if (hipFuncSetAttribute((const void*)k_stem_fwd_x3_pipe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds + 256)) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(FDET_ELAUNCH, "stem_fwd_ps: cannot reserve %zu bytes of LDS", 2 * lds + 256);
+  }
+  hipLaunchKernelGGL(k_stem_fwd_x3_pipe<true>, dim3(nblk, 1), dim3(256), 2 * lds + 256, st, a);
+  return check_launch("fdet_stem_fwd_ps");
 }
 
 int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W,

@@ -152,3 +152,12 @@ def conv3x3_ps_dgrad_unpool(dz: PsTensor, wpk_bwd, dout_pooled: torch.Tensor, ro
         raise ValueError("conv3x3_ps_dgrad_unpool: packed weight size does not match (Cout,Cin)")
     check(lib().fdet_conv3x3_ps_dgrad_unpool(dz.data, ptr(wpk_bwd), ptr(dout_pooled), ptr(route8, torch.uint8), ptr(dx),
                                              N, cin, cout, H, W, float(slope), stream()), "fdet_conv3x3_ps_dgrad_unpool")
+
+
+def stem_fwd_ps(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, y: PsTensor, k: int, stride: int, pad: int) -> None:
+    """PoolResnet stem (3 -> 64 channels, k10 s8 p2) with a PS output."""
+    N, cin, H, W = x.shape
+    F_ = int(w.shape[0])
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    _same(y, (N, F_, Ho, Wo), "stem_fwd_ps: y")
+    check(lib().fdet_stem_fwd_ps(ptr(x), ptr(w), ptr(bias), y.data, N, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_fwd_ps")

@@ -385,6 +385,11 @@ def test_gradient_entries_differ_only_through_pool_routing(fd):
         stats = {}
         for k, (c_ref, e_ref, a_ref, xin_ref, pooled) in inter.items():
             xin, a, third = saved["blocks"][k]
+            if hasattr(a, "to_f32"):                         # pre-split (PS) path: bf16 hi|lo activation, channel-innermost routing bytes
+                a = a.to_f32()
+            if third.dtype == torch.uint8 and third.dim() == 5:
+                n_, g_, hp_, wp_, _ = third.shape
+                third = third.permute(0, 1, 4, 2, 3).reshape(n_, g_ * 8, hp_, wp_)
             a_got = a.cpu()
             # LeakyReLU kinks: elements whose SIGN the kernel and the oracle disagree on (conv1's a; conv2's c below)
             flip_a = (a_got > 0) != (a_ref > 0)

@@ -173,3 +173,18 @@ def test_conv3x3_ps_pooled_block(env, shape, train):
         un[:, :, k] = torch.where(arg == k, dout, torch.zeros(()))
     un = F.fold(un.reshape(N * C, 4, -1), (H, W), 2, stride=2).reshape(N, C, H, W)
     close(dx, F.conv_transpose2d(dzp.to_f32().cpu(), w, padding=1) + un)
+
+
+@pytest.mark.parametrize("N", [1, 3])
+def test_stem_fwd_ps(env, N):
+    hp, ps = env
+    g = torch.Generator().manual_seed(N)
+    x = torch.rand(N, 3, 480, 480, generator=g)
+    w = torch.randn(64, 3, 10, 10, generator=g) * 0.05
+    b = torch.randn(64, generator=g)
+    y = ps.PsTensor(N, 64, 60, 60, "cuda")
+    ps.stem_fwd_ps(x.cuda(), w.cuda(), b.cuda(), y, 10, 8, 2)
+    ref = F.conv2d(x, w, b, stride=8, padding=2)
+    close(y.to_f32(), ref)
+    real = ps.PsTensor.from_f32(torch.full((N, 64, 60, 60), 1.0 + 2.0 ** -9, device="cuda"))
+    assert int((y.buf.view(torch.int16)[real.buf.view(torch.int16) == 0] != 0).sum()) == 0
