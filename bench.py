@@ -37,6 +37,10 @@ PEAK_HBM_GBS = 8000.0
 # SURVEY.md 8d, PoolResnet F=64 @480^2 S=10, per image: compulsory activation traffic fwd+bwd and FLOPs
 STEP_MB_PER_IMAGE_F64 = 26.90
 STEP_GFLOP_PER_IMAGE_F64 = 3.0703
+FWD_MB_PER_IMAGE_F64 = 11.81
+FWD_GFLOP_PER_IMAGE_F64 = 1.0695
+# timer groups that are launches of ONE kernel symbol (rocprofv3 --stats adds them up under that name)
+SYMBOL_OF = {"chain_fwd@15x15": "k_block_chain_x3@15x15", "chain_bwd@15x15": "k_block_chain_x3@15x15"}
 
 
 def self_launch(args) -> int:
@@ -67,6 +71,16 @@ def synth_batch(B, size, S, seed, device):
     x = torch.rand(B, 3, size, size, generator=g)
     boxes = synthetic_boxes(B, size, seed=seed + 1)
     return x.to(device), hp.encode_targets(boxes, (size, size), S, device=device), boxes
+
+
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(filters, size, S, sample_bs, steps, frames=100, warm=20):
@@ -101,6 +115,7 @@ def cpu_baseline(filters, size, S, sample_bs, steps, frames=100, warm=20):
             O.predict_image0(spec, P1, pair, 0.7, 0.01)
         dt1 = (time.perf_counter() - t1) / frames
     return {"value": round(sample_bs * steps / dt, 2), "unit": "imgs/s", "cores": threads, "kind": "port",
+            "host_logical_cpus": os.cpu_count(), "threads_used": threads, "cpu_model": cpu_model_name(),
             "sample": f"{steps} training steps (fwd+loss+bwd+Adam) at batch {sample_bs}, oracle.train_step, "
                       f"torch CPU fp32, {threads} threads, {dt:.1f} s",
             "config1_demo_path": {"ms_per_frame": round(dt1 * 1e3, 3), "fps": round(1.0 / dt1, 1), "cores": threads,
@@ -110,11 +125,15 @@ def cpu_baseline(filters, size, S, sample_bs, steps, frames=100, warm=20):
 
 
 def infer_bench(model, size, device, frames=100, warm=20):
-    """BASELINE.json: "infer FPS incl. NMS".  (1) the reference's demo path (demo_model.py:17-21): one
-    uint8 frame stacked twice, forward(predict=1) = /255 -> conv stack -> sigmoid -> decode -> NMS of
-    image 0, result read back by the host every frame; (2) batched serving: 256 uint8 frames per
-    call, decode + NMS of every image on the device, counts read back once per batch."""
+    """BASELINE.json: "infer FPS incl. NMS", at the thresholds of config 1 (0.7 / 0.01, the shipped archives' frozen values,
+    the same the host leg of cpu_baseline runs).  (1) the reference's demo path (demo_model.py:17-21): one uint8 frame
+    stacked twice, forward(predict=1) = /255 -> conv stack -> sigmoid -> decode -> NMS of image 0, result read back by the
+    host every frame; (2) batched serving: 256 uint8 frames per call, decode + NMS of every image on the device, counts
+    read back once per batch."""
     model.eval()
+    red = model.reduce_bounding_boxes
+    old_thr = (red.probability_threshold, red.iou_threshold)
+    red.probability_threshold, red.iou_threshold = 0.7, 0.01
     g = torch.Generator().manual_seed(0)
     u8 = torch.randint(0, 256, (3, size, size), dtype=torch.uint8, generator=g)
     pair = torch.stack([u8, u8]).to(device)
@@ -147,12 +166,129 @@ def infer_bench(model, size, device, frames=100, warm=20):
             outs = model.non_max_suppression(model(model._preprocess(big)))
         torch.cuda.synchronize()
         dtb = (time.perf_counter() - t0) / reps
+    red.probability_threshold, red.iou_threshold = old_thr
     model.train()
+    # roofline of the batched leg (per image): forward 1.0695 GFLOP (x3 bf16 passes), activations 11.81 MB,
+    # plus the uint8 frame read (0.69 MB) and its fp32 image written and read back (2 x 2.76 MB)
+    t_mfma = 256 * FWD_GFLOP_PER_IMAGE_F64 * 3.0 / (PEAK_BF16_MFMA_TFLOPS * 1e3) * 1e3
+    mb = 256 * (FWD_MB_PER_IMAGE_F64 + 0.69 + 2 * 2.76)
+    t_hbm = mb / 1e3 / PEAK_HBM_GBS * 1e3
     return {"demo_path_ms_per_frame": round(dt1 * 1e3, 3), "demo_path_fps": round(1.0 / dt1, 1),
             "demo_path_hipgraph_ms_per_frame": round(dtg * 1e3, 3), "demo_path_hipgraph_fps": round(1.0 / dtg, 1),
             "batched_fps": round(256 / dtb, 1), "batched_ms_per_256": round(dtb * 1e3, 3),
-            "what": "uint8 3x480x480 frames -> /255 -> PoolResnet-medium -> decode -> greedy NMS (thresholds 0.5/0.5, "
+            "batched_roofline": {"bound": "hbm" if t_hbm >= t_mfma else "mfma", "hbm_floor_ms": round(t_hbm, 3),
+                                 "mfma_floor_ms": round(t_mfma, 3), "algorithmic_mb_per_256": round(mb, 1),
+                                 "frac_of_max_floor": round(max(t_hbm, t_mfma) / (dtb * 1e3), 4)},
+            "demo_path_note": "launch-bound (2 frames: ~20 launches, one count read-back): no roofline quoted",
+            "what": "uint8 3x480x480 frames -> /255 -> PoolResnet-medium -> decode -> greedy NMS (thresholds 0.7/0.01 = config 1, "
                     "random-init weights); demo path = 2 stacked frames per call, boxes of image 0 read by the host"}
+
+
+def _time_steps(fn, warm, steps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, r
+
+
+def extra_configs(device):
+    """BASELINE.json configs 3, 4 and 5 on ONE GPU under the same clock as the headline (a few steps each): ms, img/s,
+    algorithmic work and the fraction of its floor.  The multi-GPU legs of configs 3 / 4 are the
+    driver's N > 1 runs of the headline path; these are the per-GPU shares."""
+    import numpy as np
+    import warnings
+    from fdet_amd import hotpath as hp
+    from fdet_amd.datasets.synthetic import synthetic_boxes
+    from fdet_amd.models import ModelMeta
+    from fdet_amd.models.ModelMetaSSD import ModelMetaSSD
+    from fdet_amd.models.Resnet import Resnet
+    from fdet_amd.models.SSD import SSD
+    out = {}
+    g = torch.Generator().manual_seed(3)
+
+    def floors(gflop, mb, passes, ms):
+        t_mfma = passes * gflop / (PEAK_BF16_MFMA_TFLOPS * 1e3) * 1e3
+        t_hbm = (mb / 1e3 / PEAK_HBM_GBS * 1e3) if mb else 0.0
+        return {"algorithmic_gflop": round(gflop, 1), "algorithmic_mb": round(mb, 1) if mb else None,
+                "mfma_floor_ms": round(t_mfma, 3), "hbm_floor_ms": round(t_hbm, 3) if mb else None,
+                "frac_of_max_floor": round(max(t_mfma, t_hbm) / ms, 4)}
+
+    # config 3: Resnet-64 at 640^2, S=20, 32 images per GPU (global batch 256 on 8 GPUs)
+    try:
+        B, size, S = 32, 640, 20
+        torch.manual_seed(0)
+        model = Resnet(filters=64, input_shape=(3, size, size), num_of_patches=S, num_of_residual_blocks=10).to(device).train()
+        mm = ModelMeta(model=model, lr=1e-4); mm.configure_optimizers()
+        x = torch.rand(B, 3, size, size, generator=g).to(device)
+        y = hp.encode_targets(synthetic_boxes(B, size, seed=4), (size, size), S, device=device)
+        dt, r = _time_steps(lambda: mm.fused_train_step(x, y), 2, 5)
+        out["config3_1gpu"] = {"workload": "Resnet-64 640^2 S=20, bs 32 per GPU, fwd + YoloLoss + bwd + Adam", "ms_per_step": round(dt * 1e3, 3),
+                               "imgs_per_s": round(B / dt, 1), "finite_loss": bool(torch.isfinite(r[0]).all()),
+                               **floors(B * 61.9384, B * 487.75, 3.0, dt * 1e3)}
+        del model, mm, x, y
+    except Exception as e:                                   # noqa: BLE001 (a leg must not take the headline line down)
+        out["config3_1gpu"] = {"error": repr(e)[:300]}
+    # config 4: SSD filters 16, 4774 priors, hard-negative ratio 10, 64 images per GPU (global 512 on 8)
+    try:
+        B, size = 64, 480
+        torch.manual_seed(0)
+        model = SSD(filters=16, input_shape=(3, size, size)).to(device).train()
+        mm = ModelMetaSSD(model=model, lr=1e-4); mm.configure_optimizers()
+        x = torch.rand(B, 3, size, size, generator=g).to(device)
+        y = hp.ssd_encode_targets(synthetic_boxes(B, size, seed=2), (size, size), device=device)
+        dt, r = _time_steps(lambda: mm.fused_train_step(x, y), 2, 5)
+        # forward 7.18 GMAC per image (SURVEY.md 8f rank 2); backward = data + weight gradients of the same layers
+        out["config4_1gpu"] = {"workload": "SSD filters 16, 3x480x480, 4774 priors, bs 64 per GPU, fwd + ssd_loss + bwd + Adam",
+                               "ms_per_step": round(dt * 1e3, 3), "imgs_per_s": round(B / dt, 1),
+                               "finite_loss": bool(torch.isfinite(r[0]).all()), **floors(B * 3 * 14.36, 0.0, 3.0, dt * 1e3)}
+        del model, mm, x, y
+    except Exception as e:                                   # noqa: BLE001
+        out["config4_1gpu"] = {"error": repr(e)[:300]}
+    # config 5: MobileNetV3-small backbone, bf16, bs 256 forward + batched NMS over K = 1024 candidates per image
+    try:
+        from fdet_amd.models.MobilenetV3Backbone import MobilenetV3Backbone
+        z = np.load(os.path.join(ROOT, "tests", "golden", "g13_mobilenet_weights.npz"))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = MobilenetV3Backbone(64, (3, 480, 480), 15, pretrained=False)
+        net.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files})
+        net = net.to(device).eval()
+        B, K = 256, 1024
+        x = torch.rand(B, 3, 480, 480, generator=g).to(device)
+        with torch.no_grad():
+            dt, _ = _time_steps(lambda: net(x), 2, 5)
+        eng = net._packed_engine()
+        rows = {}
+
+        class _T:                                             # algorithmic bytes per layer as the engine declares them
+            def __call__(self, label, nbytes, flops):
+                rows[label] = (nbytes, flops)
+                return self
+            def __enter__(self): return self
+            def __exit__(self, *e): return False
+        eng.timer = _T()
+        with torch.no_grad():
+            net(x)
+        eng.timer = None
+        mb = sum(v[0] for v in rows.values()) / 1e6
+        gf = sum(v[1] for v in rows.values()) / 1e9
+        c = torch.rand(B, K, 2, generator=g) * 480
+        import math
+        wh = torch.exp(torch.rand(B, K, 2, generator=g) * (math.log(128.0) - math.log(8.0)) + math.log(8.0))
+        bd = torch.cat([c - wh / 2, c + wh / 2], 2).round().to(device)
+        sd = torch.rand(B, K, generator=g).to(device)
+        cnt = torch.full((B,), K, dtype=torch.int32, device=device)
+        dtn, _ = _time_steps(lambda: hp.nms_batched(bd, sd, cnt, 0.5), 2, 5)
+        out["config5_1gpu"] = {"workload": "MobileNetV3-small backbone + head, bf16 activations, bs 256 forward; batched NMS K=1024 per image",
+                               "forward_ms": round(dt * 1e3, 3), "imgs_per_s": round(B / dt, 1), "nms_ms_per_256x1024": round(dtn * 1e3, 3),
+                               **floors(gf, mb, 1.0, dt * 1e3)}
+    except Exception as e:                                   # noqa: BLE001
+        out["config5_1gpu"] = {"error": repr(e)[:300]}
+    return out
 
 
 def kernel_source_hash() -> str:
@@ -192,6 +328,7 @@ def main():
     ap.add_argument("--filters", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the inference leg (profiling runs: its launches share kernel symbols with training)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / 4 / 5 legs")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -235,6 +372,8 @@ def main():
 
     for _ in range(args.warmup):
         mm.fused_train_step(x, y)
+    if mm._reducer is not None and mm._reducer.enabled:
+        mm._reducer.timing = []                              # HIP events around red.wait(): the exposed all-reduce time
     timer = KernelTimer()
     model.engine.timer = timer
     if world > 1:
@@ -276,15 +415,25 @@ def main():
             troof = max(t_hbm, t_mfma)
             table[k] = {"ms_per_step": round(tot / args.steps, 4), "avg_launch_ms": round(avg, 4), "bound": bound,
                         "t_roof_ms": round(troof, 4), "frac": round(troof / avg, 4) if troof > 0 else None}
-        dom = max(per, key=lambda k: per[k][1])
-        n_l, tot_ms, fl, nb = per[dom]
+        # dominant kernel SYMBOL: groups that launch the same kernel are added up (what rocprofv3 --stats shows)
+        sym = {}
+        for k, (n_l, tot, fl, nb) in per.items():
+            e = sym.setdefault(SYMBOL_OF.get(k, k), [0, 0.0, 0.0, 0.0, []])
+            e[0] += n_l; e[1] += tot; e[2] += fl * n_l; e[3] += nb * n_l; e[4].append(k)
+        dom = max(sym, key=lambda k: sym[k][1])
+        n_l, tot_ms, fl_tot, nb_tot, dom_groups = sym[dom]
+        fl, nb = fl_tot / n_l, nb_tot / n_l                   # per launch, averaged over the symbol's launches
         avg_ms = tot_ms / n_l
-        d = table[dom]
+        t_hbm_d = nb / (PEAK_HBM_GBS * 1e9) * 1e3
+        t_mfma_d = mf_mult * fl / (mf_peak * 1e12) * 1e3
+        d = {"bound": "mfma" if t_mfma_d > t_hbm_d else "hbm"}
         if d["bound"] == "hbm":
             achieved, peak, unit = nb / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
         else:
             achieved, peak, unit = mf_mult * fl / (avg_ms * 1e-3) / 1e12, mf_peak, "TFLOP/s"
-        roof = {"bound": d["bound"], "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+        sum_roof = sum(v["t_roof_ms"] * (per[k][0] / args.steps) for k, v in table.items())
+        sum_t = sum(v["ms_per_step"] for v in table.values())
+        roof = {"bound": d["bound"], "kernel": dom, "groups": dom_groups, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                 "frac": round(achieved / peak, 4), "traffic": pmc_traffic_for(dom, B, F_),
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_l // args.steps,
                 "algorithmic_mb_per_launch": round(nb / 1e6, 1), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
@@ -303,7 +452,13 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": roof, "kernels": dict(sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])),
             "final_loss": round(loss_val, 4),
+            "sum_t_roof_over_sum_t": round(sum_roof / sum_t, 4) if sum_t > 0 else None,
+            "n_ranks_seen": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
         }
+        if mm._reducer is not None and mm._reducer.timing:
+            ev = mm._reducer.timing
+            out["allreduce_ms_exposed"] = round(sum(a.elapsed_time(b) for a, b in ev) / len(ev), 4)
+            out["allreduce_backend"] = dist.get_backend() if dist.is_initialized() else None
         if F_ == 64:
             gb = STEP_MB_PER_IMAGE_F64 * B / 1e3
             gf = STEP_GFLOP_PER_IMAGE_F64 * B
@@ -314,6 +469,10 @@ def main():
                 "frac_of_max_floor": round(max(mf_mult * gf / (mf_peak * 1e3) * 1e3, gb / PEAK_HBM_GBS * 1e3) / ms, 4)}
         if world == 1 and not args.no_inference:
             out["inference"] = infer_bench(model, size, device)
+        if world == 1 and not args.no_configs:
+            del x, y
+            torch.cuda.empty_cache()
+            out["configs"] = extra_configs(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F_, size, S, sample_bs=64, steps=20)
         print(json.dumps(out))

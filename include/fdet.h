@@ -279,6 +279,7 @@ int fdet_block_tail_fwd(const float* c, const float* x, const float* drop_scale,
  *   backward: fdet_pool_route_bwd        dz2 [N,F,H,W] = unpool(dout_pooled) * drop_scale * lrelu'(c)
  *             fdet_conv3x3_dgrad_unpool  dx = conv^T(dz) + unpool(dout_pooled)      (conv1's data gradient + skip path)
  * wpk: forward / backward panels of fdet_pack_conv3x3_weights_bf16x3. */
+int fdet_conv3x3_pool_fusion_ok(int N, int Cin, int Cout, int H, int W);   /* 1: the two kernels below have a tiling for the shape */
 int fdet_conv3x3_fwd_pool_bf16x3(const float* x, const void* wpk, const float* bias, const float* skip,
                                  const float* drop_scale, float* out_pooled, unsigned char* route, int N, int Cin,
                                  int Cout, int H, int W, float slope, void* stream);

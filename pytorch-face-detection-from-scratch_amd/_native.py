@@ -72,6 +72,7 @@ SIGNATURES = {
     "fdet_conv3x3_fwd_pool_bf16x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_dgrad_unpool_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_pool_route_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_pool_fusion_ok": (_I, [_I, _I, _I, _I, _I]),
     "fdet_ps_bytes": (_SZ, [_I, _I, _I, _I]),
     "fdet_ps_image0_offset": (_SZ, [_I, _I, _I, _I]),
     "fdet_ps_from_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -208,8 +208,8 @@ class ConvStack:
             self._ws[name] = t
         return t
 
-    def _fused_pool(self, hk: int) -> bool:
-        return self.pool_fusion and hp.pool_fusion_supported(self.geo.filters, self.geo.filters, hk, hk)
+    def _fused_pool(self, hk: int, N: int = 1) -> bool:
+        return self.pool_fusion and hp.pool_fusion_supported(self.geo.filters, self.geo.filters, hk, hk, N)
 
     # ------------------------------------------------------------------ PS buffers
     def _ps_block(self, k: int) -> bool:
@@ -319,7 +319,7 @@ class ConvStack:
             with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2)):
                 hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], F_, y_full=a, slope=self.slope, x3=self.x3)
             out = torch.empty(N, F_, hk // pool, hk // pool, dtype=F32, device=dev)
-            if pool == 2 and self._fused_pool(hk):
+            if pool == 2 and self._fused_pool(hk, N):
                 # conv2 + lrelu + dropout*skip + maxpool in one kernel; c is never written, backward gets one
                 # routing byte per pooling window instead
                 c = torch.empty(N, F_, hk // 2, hk // 2, dtype=torch.uint8, device=dev) if save else None

@@ -352,7 +352,7 @@ int launch_chain(ChainArgs& a, hipStream_t st) {
   if (!chain_geometry(FCH, a.H, a.W, a.WP, a.PT, lds))
     return fail(FDET_EINVAL, "block_chain_bf16x3: unsupported map %dx%d (needs 64 channels and H*roundup4(W+1) <= 256)", a.H, a.W);
   if ((size_t)a.N * FCH * a.H * a.W >= ((size_t)1 << 31)) return fail(FDET_EINVAL, "block_chain_bf16x3: tensor too large");
-  (void)hipFuncSetAttribute((const void*)k_block_chain_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  { if (int rc_ = set_lds_attr((const void*)k_block_chain_x3, (size_t)(lds), __func__)) return rc_; }
   hipLaunchKernelGGL(k_block_chain_x3, dim3(a.N), dim3(NTHR), lds, st, a);
   return check_launch("fdet_block_chain_bf16x3");
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "../../include/fdet.h"
 
@@ -26,6 +27,18 @@ inline int check_launch(const char* what) {
   if (e != hipSuccess) return fail(FDET_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
   return FDET_OK;
 }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) with its result checked (a kernel that needs more than 64 KB of LDS
+// fails at launch with an unhelpful error otherwise)
+inline int set_lds_attr(const void* kern, size_t lds, const char* what) {
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(FDET_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", what, lds);
+  }
+  return FDET_OK;
+}
+// environment switch read once per call site (launch paths are hot on the launch-bound demo path)
+#define FDET_ENV_ONCE(NAME) ([]() -> const char* { static const char* v_ = getenv(NAME); return v_; }())
 
 constexpr int WAVE = 64;
 

@@ -223,13 +223,11 @@ k_pack3x3(const float* __restrict__ w, int Cout, int Cin, int CoP, int CiP, floa
 
 template <int MT, int NT>
 int launch_conv_vw(const ConvArgs& a, int vw, size_t lds, dim3 grid, hipStream_t st) {
-  auto set = [&](const void* f) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  };
+  auto set = [&](const void* f) -> int { return lds > 64 * 1024 ? set_lds_attr(f, lds, "conv3x3") : FDET_OK; };
 
-  if (vw == 4) { set((const void*)k_conv3x3<MT, NT, 4>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 4>), grid, dim3(NTHR), lds, st, a); }
-  else if (vw == 2) { set((const void*)k_conv3x3<MT, NT, 2>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 2>), grid, dim3(NTHR), lds, st, a); }
-  else { set((const void*)k_conv3x3<MT, NT, 1>); hipLaunchKernelGGL((k_conv3x3<MT, NT, 1>), grid, dim3(NTHR), lds, st, a); }
+  if (vw == 4) { if (int rc = set((const void*)k_conv3x3<MT, NT, 4>)) return rc; hipLaunchKernelGGL((k_conv3x3<MT, NT, 4>), grid, dim3(NTHR), lds, st, a); }
+  else if (vw == 2) { if (int rc = set((const void*)k_conv3x3<MT, NT, 2>)) return rc; hipLaunchKernelGGL((k_conv3x3<MT, NT, 2>), grid, dim3(NTHR), lds, st, a); }
+  else { if (int rc = set((const void*)k_conv3x3<MT, NT, 1>)) return rc; hipLaunchKernelGGL((k_conv3x3<MT, NT, 1>), grid, dim3(NTHR), lds, st, a); }
   return check_launch("fdet_conv3x3");
 }
 

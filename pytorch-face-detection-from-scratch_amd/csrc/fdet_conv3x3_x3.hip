@@ -8,6 +8,7 @@
 // This file: weight-panel packing, tile selection and the C-ABI entry points.  The kernels live in
 // fdet_conv3x3_x3_kernel.inc, compiled once per epilogue mode (fdet_conv3x3_x3_m*.hip).
 #include "fdet_conv3x3_x3.h"
+#include <algorithm>
 
 namespace {
 
@@ -281,6 +282,18 @@ static int run_x3_pooled(const ConvArgs& a, const PoolArgs& q, hipStream_t st) {
     if (rc != 1) return rc;
   }
   return fdet_x3_pp_run(a, q, st);
+}
+
+// 1 when the fused pooled-block kernels (fdet_conv3x3_fwd_pool_bf16x3 / fdet_conv3x3_dgrad_unpool_bf16x3) have a tiling
+// for the shape -- the same conditions fdet_x3_sb_pool_run checks before it launches (even map of <= 62 columns, channel
+// multiples, 32-bit element offsets, < 2^20 (image, band) tiles) -- so a caller can choose the separate conv + tail
+// kernels up front instead of catching FDET_EINVAL.
+extern "C" int fdet_conv3x3_pool_fusion_ok(int N, int Cin, int Cout, int H, int W) {
+  if (N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || W > 62 || Cin % 16 != 0 || Cout % 32 != 0 || Cin % 32 != 0) return 0;
+  if ((size_t)N * (size_t)std::max(Cin, Cout) * H * W >= ((size_t)1 << 31)) return 0;
+  const int WP = W <= 31 ? 32 : 64, R = std::min(256 / WP, (H + 1) & ~1);
+  const long bands = (long)N * ((H + R - 1) / R);
+  return bands < (1 << 20) ? 1 : 0;
 }
 
 extern "C" int fdet_conv3x3_fwd_pool_bf16x3(const float* x, const void* wpk, const float* bias, const float* skip,

@@ -262,10 +262,10 @@ extern "C" int fdet_head_fwd(const float* x, const float* drop_scale, const floa
   FDET_REQUIRE(head_geo(F, H, W, k, pad, g, part), "head_fwd: activation %dx%d too large for LDS staging", H, W);
   const size_t lds = ((size_t)g.FC * g.HP * g.WP + part) * 4;
   if (k == 6) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_head_fwd<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) { if (int rc_ = set_lds_attr((const void*)k_head_fwd<6>, (size_t)(lds), __func__)) return rc_; }
     hipLaunchKernelGGL(k_head_fwd<6>, dim3(N), dim3(HT), lds, (hipStream_t)stream, x, drop_scale, w, bias, y, g);
   } else {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_head_fwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) { if (int rc_ = set_lds_attr((const void*)k_head_fwd<3>, (size_t)(lds), __func__)) return rc_; }
     hipLaunchKernelGGL(k_head_fwd<3>, dim3(N), dim3(HT), lds, (hipStream_t)stream, x, drop_scale, w, bias, y, g);
   }
   return check_launch("fdet_head_fwd");
@@ -298,10 +298,10 @@ extern "C" int fdet_head_bwd(const float* x, const float* drop_scale, const floa
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_head_pack, dim3((5 * kk * F + 255) / 256), dim3(256), 0, st, w, F, kk, wT);
   if (k == 6) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_head_bwd<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) { if (int rc_ = set_lds_attr((const void*)k_head_bwd<6>, (size_t)(lds), __func__)) return rc_; }
     hipLaunchKernelGGL(k_head_bwd<6>, dim3(N), dim3(HT), lds, st, x, drop_scale, wT, y, dy, dx, wsW, wsb, g);
   } else {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_head_bwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) { if (int rc_ = set_lds_attr((const void*)k_head_bwd<3>, (size_t)(lds), __func__)) return rc_; }
     hipLaunchKernelGGL(k_head_bwd<3>, dim3(N), dim3(HT), lds, st, x, drop_scale, wT, y, dy, dx, wsW, wsb, g);
   }
   if (int rc = check_launch("fdet_head_bwd")) return rc;

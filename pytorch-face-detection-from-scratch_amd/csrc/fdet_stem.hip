@@ -337,16 +337,16 @@ extern "C" int fdet_stem_fwd(const float* x, const float* w, const float* bias, 
                "stem_fwd: unsupported stem Cin=%d k=%d stride=%d pad=%d W=%d (built: 3ch k10s8p2, k3s2p1)", Cin, k,
                stride, pad, W);
   hipStream_t st = (hipStream_t)stream;
-  if (stem_mfma_ok(Cin, F, H, W, k, stride, pad) && !getenv("FDET_STEM_VALU")) return stem_mfma_fwd(x, w, bias, y, N, F, H, W, st);
+  if (stem_mfma_ok(Cin, F, H, W, k, stride, pad) && !FDET_ENV_ONCE("FDET_STEM_VALU")) return stem_mfma_fwd(x, w, bias, y, N, F, H, W, st);
   if (ws_bytes < p.pack_floats * 4) return fail(FDET_EWORKSPACE, "stem_fwd: workspace %zu < %zu", ws_bytes, p.pack_floats * 4);
   float* wpk = (float*)ws;
   hipLaunchKernelGGL(k_stem_pack, dim3((p.KK * p.FP + 255) / 256), dim3(256), 0, st, w, F, p.FP, p.KK, wpk);
   dim3 grid(N * p.Ho);
   if (k == 10) {
-    if (p.lds_fwd > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_stem_fwd<10, 8, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fwd);
+    if (p.lds_fwd > 64 * 1024) { if (int rc_ = set_lds_attr((const void*)k_stem_fwd<10, 8, 2, 3>, (size_t)p.lds_fwd, __func__)) return rc_; }
     hipLaunchKernelGGL((k_stem_fwd<10, 8, 2, 3>), grid, dim3(256), p.lds_fwd, st, x, wpk, bias, y, F, p.FP, H, W, p.Ho, p.Wo, p.BXS);
   } else {
-    if (p.lds_fwd > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_stem_fwd<3, 2, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fwd);
+    if (p.lds_fwd > 64 * 1024) { if (int rc_ = set_lds_attr((const void*)k_stem_fwd<3, 2, 1, 3>, (size_t)p.lds_fwd, __func__)) return rc_; }
     hipLaunchKernelGGL((k_stem_fwd<3, 2, 1, 3>), grid, dim3(256), p.lds_fwd, st, x, wpk, bias, y, F, p.FP, H, W, p.Ho, p.Wo, p.BXS);
   }
   return check_launch("fdet_stem_fwd");
@@ -388,7 +388,7 @@ extern "C" int fdet_stem_wgrad(const float* x, const float* dy, float* dW, float
   StemPlan p;
   FDET_REQUIRE(stem_plan(N, Cin, F, H, W, k, stride, pad, p), "stem_wgrad: unsupported stem k=%d stride=%d pad=%d", k, stride, pad);
   hipStream_t st = (hipStream_t)stream;
-  if (stem_mfma_ok(Cin, F, H, W, k, stride, pad) && !getenv("FDET_STEM_VALU")) {
+  if (stem_mfma_ok(Cin, F, H, W, k, stride, pad) && !FDET_ENV_ONCE("FDET_STEM_VALU")) {
     if (ws_bytes < stem_mfma_ws_floats(N, F, H, W) * 4) return fail(FDET_EWORKSPACE, "stem_wgrad: workspace too small");
     return stem_mfma_wgrad(x, dy, dW, db, (float*)ws, N, F, H, W, st);
   }
@@ -397,9 +397,9 @@ extern "C" int fdet_stem_wgrad(const float* x, const float* dy, float* dW, float
   float* wsb = wsW + (size_t)p.nblk * p.KK * p.FP;
   dim3 grid(p.nblk, p.FP / 64);
   if (k == 10) {
-    if (p.lds_wg > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_stem_wgrad<10, 8, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_wg);
+    if (p.lds_wg > 64 * 1024) { if (int rc_ = set_lds_attr((const void*)k_stem_wgrad<10, 8, 2, 3>, (size_t)p.lds_wg, __func__)) return rc_; }
     hipLaunchKernelGGL((k_stem_wgrad<10, 8, 2, 3>), grid, dim3(256), p.lds_wg, st, x, dy, wsW, wsb, N, F, p.FP, H, W, p.Ho, p.Wo, p.XS, p.DS);
-  } else if (H % 2 == 0 && W % 2 == 0 && p.Wo % 4 == 0 && !getenv("FDET_STEM_K3_GENERIC")) {
+  } else if (H % 2 == 0 && W % 2 == 0 && p.Wo % 4 == 0 && !FDET_ENV_ONCE("FDET_STEM_K3_GENERIC")) {
     // scalar-fed kernel: items = (row, 64-column segment), four 8-wave workgroups per CU, one slab per workgroup
     const int nseg = (p.Wo + 63) / 64;
     const int nitems = N * p.Ho * nseg;
@@ -411,7 +411,7 @@ extern "C" int fdet_stem_wgrad(const float* x, const float* dy, float* dW, float
     hipLaunchKernelGGL(k_stem_reduce, dim3((p.KK * p.FP + p.FP + 15) / 16), dim3(256), 0, st, wsW, wsb, nb, p.KK, F, p.FP, dW, db);
     return check_launch("fdet_stem_wgrad(reduce)");
   } else {
-    if (p.lds_wg > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_stem_wgrad<3, 2, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_wg);
+    if (p.lds_wg > 64 * 1024) { if (int rc_ = set_lds_attr((const void*)k_stem_wgrad<3, 2, 1, 3>, (size_t)p.lds_wg, __func__)) return rc_; }
     hipLaunchKernelGGL((k_stem_wgrad<3, 2, 1, 3>), grid, dim3(256), p.lds_wg, st, x, dy, wsW, wsb, N, F, p.FP, H, W, p.Ho, p.Wo, p.XS, p.DS);
   }
   if (int rc = check_launch("fdet_stem_wgrad")) return rc;

@@ -260,7 +260,7 @@ int stem_mfma_fwd(const float* x, const float* w, const float* bias, float* y, i
   const int FP = (F + 63) / 64 * 64;
   const int nblk = a.nrows < 256 ? a.nrows : 256;
   const size_t lds = (size_t)XT * 4;
-  (void)hipFuncSetAttribute((const void*)k_stem_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  { if (int rc_ = set_lds_attr((const void*)k_stem_fwd_mfma, (size_t)(lds), __func__)) return rc_; }
   hipLaunchKernelGGL(k_stem_fwd_mfma, dim3(nblk, FP / 64), dim3(256), lds, st, a);
   return check_launch("fdet_stem_fwd(mfma)");
 }
@@ -274,7 +274,7 @@ int stem_mfma_wgrad(const float* x, const float* dy, float* dW, float* db, float
   const int nblk = a.nrows < 256 ? a.nrows : 256;
   a.ws = ws; a.wsb = ws + (size_t)nblk * FP * 320;
   const size_t lds = (size_t)(XT + 64 * DYS) * 4;
-  (void)hipFuncSetAttribute((const void*)k_stem_wgrad_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  { if (int rc_ = set_lds_attr((const void*)k_stem_wgrad_mfma, (size_t)(lds), __func__)) return rc_; }
   hipLaunchKernelGGL(k_stem_wgrad_mfma, dim3(nblk, FP / 64), dim3(256), lds, st, a);
   if (int rc = check_launch("fdet_stem_wgrad(mfma)")) return rc;
   hipLaunchKernelGGL(k_stem_mfma_reduce, dim3(5, F), dim3(256), 0, st, a.ws, a.wsb, nblk, F, FP, dW, db);

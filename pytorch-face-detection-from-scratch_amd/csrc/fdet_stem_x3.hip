@@ -768,7 +768,7 @@ int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int
   const int FP = (F + 63) / 64 * 64;
   const int nblk = a.nrows < 256 ? a.nrows : 256;
   const size_t lds = (size_t)NROW * RL * 2 * 2;
-  const char* e = getenv("FDET_STEM_PIPE");
+  const char* e = FDET_ENV_ONCE("FDET_STEM_PIPE");
   // pipelined kernel: 32-bit byte offsets into x and y (FDET_STEM_PIPE=0 keeps the single-tile kernel)
   if (!(e && e[0] == '0') && (size_t)N * CIN * H * W < ((size_t)1 << 29) && (size_t)N * F * a.Ho * a.Wo < ((size_t)1 << 29)) {
     if (hipFuncSetAttribute((const void*)k_stem_fwd_x3_pipe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds + 256)) != hipSuccess) {
@@ -778,7 +778,7 @@ int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int
     hipLaunchKernelGGL(k_stem_fwd_x3_pipe<false>, dim3(nblk, FP / 64), dim3(256), 2 * lds + 256, st, a);
     return check_launch("fdet_stem_fwd(bf16x3 pipelined)");
   }
-  (void)hipFuncSetAttribute((const void*)k_stem_fwd_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  { if (int rc_ = set_lds_attr((const void*)k_stem_fwd_x3, (size_t)(lds), __func__)) return rc_; }
   hipLaunchKernelGGL(k_stem_fwd_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
   return check_launch("fdet_stem_fwd(bf16x3)");
 }
@@ -811,15 +811,15 @@ int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* 
   const int nblk = a.nrows < 256 ? a.nrows : 256;
   a.ws = ws; a.wsb = ws + (size_t)nblk * FP * 320;
   const size_t lds = ((size_t)NPLANE * PE * 2 + 64 * DL * 2) * 2;
-  const char* e = getenv("FDET_STEM_PIPE");
+  const char* e = FDET_ENV_ONCE("FDET_STEM_PIPE");
   const bool pipe = !(e && e[0] == '0') && a.Wo <= 60 && a.Wo > 48 && (size_t)N * CIN * H * W < ((size_t)1 << 29) &&
                     (size_t)N * F * a.Ho * a.Wo < ((size_t)1 << 29);
   if (pipe) {     // pipelined: two plane tiles of 9-chunk planes, exactly four 16-column k-steps (48 < Wo <= 60), 32-bit byte offsets
     const size_t lds2 = ((size_t)2 * TILEP + 2 * 64 * DL + 8 * PEP) * 2;
-    (void)hipFuncSetAttribute((const void*)k_stem_wgrad_x3_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    { if (int rc_ = set_lds_attr((const void*)k_stem_wgrad_x3_pipe, (size_t)(lds2), __func__)) return rc_; }
     hipLaunchKernelGGL(k_stem_wgrad_x3_pipe, dim3(nblk, FP / 64), dim3(256), lds2, st, a);
   } else {
-    (void)hipFuncSetAttribute((const void*)k_stem_wgrad_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { if (int rc_ = set_lds_attr((const void*)k_stem_wgrad_x3, (size_t)(lds), __func__)) return rc_; }
     hipLaunchKernelGGL(k_stem_wgrad_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
   }
   if (int rc = check_launch("fdet_stem_wgrad(bf16x3)")) return rc;

@@ -452,14 +452,16 @@ WgPlanG plan_wgrad_generic(int N, int Cin, int Cout, int H, int W) {
 
 
 template <int MTC, int CG>
-void launch_wg(const WgArgs& a, const WgPlan& p, dim3 grid, hipStream_t st) {
+int launch_wg(const WgArgs& a, const WgPlan& p, dim3 grid, hipStream_t st) {
+  int rc = FDET_OK;
   auto go = [&](auto kern) {
-    if (p.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-    hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds, st, a);
+    if (p.lds > 64 * 1024) rc = set_lds_attr((const void*)kern, p.lds, "conv3x3_wgrad");
+    if (rc == FDET_OK) hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds, st, a);
   };
   if (p.vw == 4) go(k_wgrad3x3<MTC, CG, 4>);
   else if (p.vw == 2) go(k_wgrad3x3<MTC, CG, 2>);
   else go(k_wgrad3x3<MTC, CG, 1>);
+  return rc;
 }
 
 }  // namespace
@@ -486,10 +488,12 @@ extern "C" int fdet_conv3x3_wgrad(const float* x, const float* dz, float* dW, fl
     a.VR = p.VR; a.CSZ = p.CSZ; a.CSX = p.CSX; a.nbands = p.nbands;
     a.magic_h1 = magic_of(H + 1);
     dim3 grid(p.nblk, p.CiP / (p.CG * 32), p.CoP / (p.MTC * 32));
-    if (p.MTC == 2 && p.CG == 2) launch_wg<2, 2>(a, p, grid, st);
-    else if (p.MTC == 2) launch_wg<2, 1>(a, p, grid, st);
-    else if (p.CG == 2) launch_wg<1, 2>(a, p, grid, st);
-    else launch_wg<1, 1>(a, p, grid, st);
+    int lrc;
+    if (p.MTC == 2 && p.CG == 2) lrc = launch_wg<2, 2>(a, p, grid, st);
+    else if (p.MTC == 2) lrc = launch_wg<2, 1>(a, p, grid, st);
+    else if (p.CG == 2) lrc = launch_wg<1, 2>(a, p, grid, st);
+    else lrc = launch_wg<1, 1>(a, p, grid, st);
+    if (lrc != FDET_OK) return lrc;
     if (int rc = check_launch("fdet_conv3x3_wgrad")) return rc;
     hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3(9, (Cout + 3) / 4), dim3(1024), 0, st, a.ws, a.wsb, p.nslab, Cout, Cin, p.CoP,
                        p.CiP, dW, db);
@@ -506,10 +510,10 @@ extern "C" int fdet_conv3x3_wgrad(const float* x, const float* dz, float* dW, fl
   a.VR = g.VR; a.CSZ = g.CSZ; a.CSX = g.CSX; a.nbands = g.nbands;
   dim3 grid(g.nblk, g.CiP / 32, g.CoP / (g.MT * 32));
   if (g.MT == 2) {
-    if (g.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad3x3_generic<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+    if (g.lds > 64 * 1024) { if (int rc_ = set_lds_attr((const void*)k_wgrad3x3_generic<2>, (size_t)(g.lds), __func__)) return rc_; }
     hipLaunchKernelGGL(k_wgrad3x3_generic<2>, grid, dim3(256), g.lds, st, a);
   } else {
-    if (g.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad3x3_generic<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+    if (g.lds > 64 * 1024) { if (int rc_ = set_lds_attr((const void*)k_wgrad3x3_generic<1>, (size_t)(g.lds), __func__)) return rc_; }
     hipLaunchKernelGGL(k_wgrad3x3_generic<1>, grid, dim3(256), g.lds, st, a);
   }
   if (int rc = check_launch("fdet_conv3x3_wgrad(generic)")) return rc;

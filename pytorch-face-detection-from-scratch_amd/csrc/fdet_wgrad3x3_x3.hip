@@ -752,7 +752,7 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   p.vw = (W % 4 == 0) ? 4 : (W % 2 == 0 ? 2 : 1);
   // four narrow rows per 16-lane group: opt-in (FDET_WGRAD_PACK=1) -- measured SLOWER than the
   // dword-per-lane staging on the 15x15 layers (0.64 vs 0.50 ms per 16 layers), kept for tuning
-  p.pack = (W >= 4 && W <= 16 && getenv("FDET_WGRAD_PACK") != nullptr) ? 1 : 0;
+  p.pack = (W >= 4 && W <= 16 && FDET_ENV_ONCE("FDET_WGRAD_PACK") != nullptr) ? 1 : 0;
   if (p.pack) p.vw = 4;
   p.NSEG = 1; p.CW = W;
   if (W / p.vw > 16 && p.vw == 4) { p.CW = 56; p.NSEG = (W + 55) / 56; }     // column segments (14 vector lanes)
@@ -786,14 +786,14 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
   // pipelined kernel: 64 output channels, bands of exactly 128 positions (R = 128 / P rows = the rows one
   // register set holds), two LDS tiles.  FDET_WGRAD_PIPE=0 keeps the single-tile kernel.
   {
-    const char* e = getenv("FDET_WGRAD_PIPE");
+    const char* e = FDET_ENV_ONCE("FDET_WGRAD_PIPE");
     const int rp = 32 / (4 * p.vw);
     const bool lpr32 = p.P == 32 && p.NSEG == 1 && !p.pack && W <= 32;      // one-float lanes, 32 per row (30x30)
     p.pipe = p.ok && p.MTC == 2 && p.NSEG == 1 && !p.pack && ((p.vw != 2 && rp * p.P == 128) || lpr32) && rows_total >= 8 &&
              (size_t)N * std::max(Cin, Cout) * H * W < ((size_t)1 << 29) && !(e && e[0] == '0');   // 32-bit byte offsets
     p.lpr32 = p.pipe && lpr32;
     {
-      const char* e4 = getenv("FDET_WGRAD_PK4");
+      const char* e4 = FDET_ENV_ONCE("FDET_WGRAD_PK4");
       // rows of 13..16 floats (one-float form, 16 lanes) or 29..32 floats (the 32-lane form): float4 quads instead
       p.pk4 = p.pipe && !(e4 && e4[0] == '0') && ((!p.lpr32 && p.vw == 1 && W >= 13 && W <= 16 && p.P == 16) || (p.lpr32 && W >= 29 && p.P == 32));
     }
@@ -815,16 +815,17 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
 }
 
 template <int MTC>
-void launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) {
+int launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) {
+  int rc = FDET_OK;
   auto go = [&](auto kern) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-    hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds, st, a);
+    rc = set_lds_attr((const void*)kern, p.lds, "conv3x3_wgrad_bf16x3");
+    if (rc == FDET_OK) hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds, st, a);
   };
   if (p.pipe && MTC == 2) {
 #ifdef FDET_WG_DBG
-    const char* e = getenv("FDET_WG_DBG");
+    const char* e = FDET_ENV_ONCE("FDET_WG_DBG");
     const int dbg = e ? atoi(e) : 0;
-#define WG_DBG_CASE(D) if (dbg == D && !p.lpr32) { if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4, D>); else go(k_wgrad3x3_x3_pipe<1, D>); return; }
+#define WG_DBG_CASE(D) if (dbg == D && !p.lpr32) { if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4, D>); else go(k_wgrad3x3_x3_pipe<1, D>); return rc; }
     WG_DBG_CASE(1) WG_DBG_CASE(3) WG_DBG_CASE(8) WG_DBG_CASE(9) WG_DBG_CASE(24) WG_DBG_CASE(40) WG_DBG_CASE(73)
 #endif
     if (p.lpr32 && p.pk4) go(k_wgrad3x3_x3_pipe<4, 0, 32, 1>);
@@ -837,6 +838,7 @@ void launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) 
   else if (p.vw == 4) go(k_wgrad3x3_x3<MTC, 4, false>);
   else if (p.vw == 2) go(k_wgrad3x3_x3<MTC, 2, false>);
   else go(k_wgrad3x3_x3<MTC, 1, false>);
+  return rc;
 }
 
 }  // namespace
@@ -855,7 +857,7 @@ static int run_wg_x3(const float* const* xs, const float* const* dzs, float* con
   a.VR = p.VR; a.QZ = p.QZ; a.PX = p.PX; a.Kext = p.Kext; a.nbands = p.nbands; a.magic_h1 = magic_of(H + 1);
   a.L = L; a.ncob = p.CoP / (p.MTC * 32); a.NSEG = p.NSEG; a.CW = p.CW;
   dim3 grid(p.nblk, p.CiP / 32, a.ncob * L);
-  if (p.MTC == 2) launch_x3<2>(a, p, grid, st); else launch_x3<1>(a, p, grid, st);
+  if (int rc = p.MTC == 2 ? launch_x3<2>(a, p, grid, st) : launch_x3<1>(a, p, grid, st)) return rc;
   if (int rc = check_launch("fdet_conv3x3_wgrad_bf16x3")) return rc;
   hipLaunchKernelGGL(k_wgx3_reduce, dim3(9, (Cout + 3) / 4, L), dim3(1024), 0, st, a.ws, a.wsb, p.nblk, Cout, Cin, p.CoP,
                      p.CiP, r);

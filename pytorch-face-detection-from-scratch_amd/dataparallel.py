@@ -41,7 +41,7 @@ def sync_parameters(flat_param: torch.Tensor, group=None, check: bool = True) ->
     """Start-of-training hand-shake: broadcast rank 0's flat parameter buffer (ranks then hold bit-identical
     weights whatever their seeds were) and, with `check`, verify it by an all-reduced checksum."""
     rank, world = rank_world(group)
-    if world == 1:
+    if world == 1 and not dp_active(group):
         return
     dist.broadcast(flat_param, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     if check:
@@ -61,6 +61,21 @@ def shard_range(batch: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def dp_forced() -> bool:
+    """FDET_DP_FORCE=1: run the gradient exchange even in a one-rank process group (the all-reduce is then the identity).
+    This is how the RCCL path -- init with device_id, async all-reduce on slices of the flat gradient, stream-ordered
+    wait -- is exercised on a one-GPU box (tests/test_gpu_rccl.py)."""
+    import os
+    return os.environ.get("FDET_DP_FORCE", "0") == "1"
+
+
+def dp_active(group=None) -> bool:
+    """A process group exists and has more than one rank (or the exchange is forced, see dp_forced)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or dp_forced()
+
+
 class GradBucketReducer:
     def __init__(self, flat_grad: torch.Tensor, split_offset: int, group=None):
         """`split_offset`: index into flat_grad where the late (low-resolution) bucket starts."""
@@ -70,7 +85,8 @@ class GradBucketReducer:
         self.split = split_offset
         self.group = group
         self._pending: List = []
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = dp_active(group)
+        self.timing = None           # optional [(event before wait, event after wait)] list: exposed all-reduce time
 
     def launch_tail(self):
         """Gradients of [split, end) are final: start their all-reduce (async)."""
@@ -84,9 +100,18 @@ class GradBucketReducer:
                                                  async_op=True))
 
     def wait(self):
+        """Make the current stream wait for the launched all-reduces (no host block).  With `timing` set to a list, a
+        pair of HIP events brackets the wait on the current stream: what the step could NOT hide behind backward."""
+        ev = None
+        if self.timing is not None and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._pending:
             w.wait()
         self._pending = []
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
 
 
 def allreduce_scalars(t: torch.Tensor, group=None) -> torch.Tensor:

@@ -396,9 +396,10 @@ def conv3x3_dgrad(dz, wpk_bwd, cin: int, dx, act=None, add=None, slope: float = 
           "fdet_conv3x3_dgrad")
 
 
-def pool_fusion_supported(cout: int, cin: int, H: int, W: int) -> bool:
-    """Pooled residual blocks whose tail runs inside the conv epilogues (fdet_conv3x3_fwd_pool_bf16x3)."""
-    return cout % 32 == 0 and cin % 16 == 0 and H % 2 == 0 and W % 2 == 0 and H >= 2 and 2 <= W <= 62
+def pool_fusion_supported(cout: int, cin: int, H: int, W: int, N: int = 1) -> bool:
+    """Pooled residual blocks whose tail runs inside the conv epilogues (fdet_conv3x3_fwd_pool_bf16x3): the library's own
+    plan check (fdet_conv3x3_pool_fusion_ok), batch-size limits included when N is given."""
+    return bool(lib().fdet_conv3x3_pool_fusion_ok(int(N), int(cin), int(cout), int(H), int(W)))
 
 
 def conv3x3_fwd_pool(x, wpk, bias, skip, drop_scale, out_pooled, route, slope: float = 0.2):

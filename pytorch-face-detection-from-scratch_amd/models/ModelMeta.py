@@ -121,14 +121,14 @@ class ModelMeta(_Base):
         return lsum, y_hat, metrics
 
     # ------------------------------------------------------------------ export (train_model.py:61)
-    if not _HAVE_PL:
-        def to_torchscript(self, file_path=None, method="script", example_inputs=None, **kwargs):
-            """Lightning's `LightningModule.to_torchscript`: the scripted inference path of the wrapped model (custom
-            `fdet::` operators, torchscript.py), saved to `file_path` when given."""
-            if method != "script":
-                raise ValueError("only method='script' is supported (tracing records nothing of a custom-operator forward)")
-            from ..torchscript import to_torchscript
-            return to_torchscript(self.model, file_path)
+    def to_torchscript(self, file_path=None, method="script", example_inputs=None, **kwargs):
+        """`LightningModule.to_torchscript` (train_model.py:61) -- overridden with Lightning installed too: its default
+        would torch.jit.script the whole module, whose forward is ctypes / HIP launches.  Returns the scripted inference
+        path of the wrapped model (custom `fdet::` operators, torchscript.py), saved to `file_path` when given."""
+        if method != "script":
+            raise ValueError("only method='script' is supported (tracing records nothing of a custom-operator forward)")
+        from ..torchscript import to_torchscript
+        return to_torchscript(self.model, file_path)
 
     # ------------------------------------------------------------------ epoch hooks (ModelMeta.py:241-322)
     def format_metrics(self, epoch_outputs, training=True):

@@ -9,9 +9,10 @@ import torch
 from .. import hotpath as hp
 import torch.distributed as dist
 
-from ..dataparallel import GradBucketReducer, rank_world, sync_parameters
+from ..dataparallel import GradBucketReducer, dp_active, rank_world, sync_parameters
 from ..losses.SSDLoss import ssd_loss
 from ..optim import SAMSGD
+from .ModelMeta import ModelMeta as _YoloMeta
 
 try:                                                     # pragma: no cover - not in this image
     from pytorch_lightning import LightningModule as _Base
@@ -29,6 +30,9 @@ class ModelMetaSSD(_Base):
         self.automatic_optimization = True
         self.log_path = log_path
         self.opt = None
+        self.epoch_metrics = None
+        if not _HAVE_PL:
+            self.current_epoch = 0
         self._reducer = None
         self._logged = {}
 
@@ -72,6 +76,13 @@ class ModelMetaSSD(_Base):
     def test_step(self, batch, batch_idx):
         return self.step(batch, batch_idx, validation=True)
 
+    # ------------------------------------------------------------------ epoch hooks (ModelMetaSSD.py:245-327)
+    # line for line the hooks of models/ModelMeta.py:241-322 in the reference too: one implementation serves both
+    format_metrics = _YoloMeta.format_metrics
+    training_epoch_end = _YoloMeta.training_epoch_end
+    validation_epoch_end = _YoloMeta.validation_epoch_end
+    test_epoch_end = _YoloMeta.test_epoch_end
+
     def fused_train_step(self, x, y):
         """One optimisation step on (x (N,3,480,480) in [0,1], y (N,4774,5)); returns (loss (1,), y_hat)."""
         if self.opt is None:
@@ -83,18 +94,22 @@ class ModelMetaSSD(_Base):
             raise RuntimeError("optimizer parameter order differs from the SSD stack's")
         P = {n: p.data for n, p in zip(names, params)}
         G = {n: sp.view(sp.grad, i) for i, n in enumerate(names)}
-        world = rank_world()[1]
-        if world > 1 and self._reducer is None:
-            # one process per GPU: rank 0's parameters everywhere, then one SUM all-reduce of the flat gradient per step
-            if not (dist.is_available() and dist.is_initialized()):
-                raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: data-parallel SSD training "
-                                   "needs a process group (bench.py / torch.distributed.run set one up)")
+        import os
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: data-parallel SSD training "
+                               "needs a process group (bench.py / torch.distributed.run set one up)")
+        dp = dp_active()
+        if dp and (self._reducer is None or self._reducer.flat.data_ptr() != sp.grad.data_ptr()):
+            # one process per GPU: rank 0's parameters everywhere, then one SUM all-reduce of the flat gradient per step.
+            # Re-created whenever the flat buffers were re-homed (model.to(), load_state_dict(assign=True), a resume):
+            # a reducer bound to the OLD gradient buffer would reduce stale memory and let the ranks drift apart.
             sync_parameters(sp.flat)
             eng.mark_params_dirty()
+            P = {n: p.data for n, p in zip(names, params)}
             self._reducer = GradBucketReducer(sp.grad, 0)
         masks = model._draw_masks(x.shape[0], x.device) if model.training else None
         y_hat, saved = eng.forward(x, P, masks, save=True)
-        if world > 1:
+        if dp:
             # ssd_loss divides by the positive count of the WHOLE batch (losses/SSDLoss.py:86): the three batch sums are
             # exchanged (24 bytes) BEFORE the gradient is scaled and back-propagated, so the N-rank step optimises
             # exactly the single-process objective on the concatenated batch
@@ -104,7 +119,7 @@ class ModelMetaSSD(_Base):
         else:
             loss, dy, _ = hp.ssd_loss_fwd_bwd(y_hat, y, 10, want_grad=True)
         eng.backward(saved, dy, P, G)
-        if world > 1:
+        if dp:
             self._reducer.launch_tail()
             self._reducer.wait()
         self.opt.step(grads_in_flat=True)

@@ -205,6 +205,56 @@ def test_whole_backbone_features_accumulated_error(golden):
         assert err <= 0.05 * rms, (err, rms)
 
 
+def test_boxes_against_oracle_away_from_the_threshold(golden):
+    """Box level (parity UNPINNED: the fp32 oracle is a restatement, no reference output exists).  The bf16 stack's maps
+    are within 0.03 of the oracle's (test above), so: (1) every cell whose oracle confidence is farther than 0.03 from the
+    probability threshold is selected / rejected exactly as the oracle does; (2) the boxes decoded from cells selected by
+    both (datasets/utils.py:107-162 arithmetic on either map) differ by 3 px on average, 99 % of the coordinates by at
+    most 0.03 of the image size + 1 rounding pixel, none by more than a tenth of the image (images 2 and 3 are outside
+    the [0,1] noise the 0.03 map bound was measured on; observed: mean 0.8 px, worst 33 px).  Cells inside the 0.03 band -- and hence NMS keep-sets that hinge on them -- may differ:
+    that is the stated consequence of bf16 activations (inference only)."""
+    from oracle import mobilenet_oracle as MO
+    P = golden("g13_mobilenet_weights")
+    net = _model(P)
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(4, 3, 480, 480, generator=g)
+    x[1] = F.avg_pool2d(x[1:2], 9, 1, 4)[0]
+    x[2] = F.avg_pool2d(x[2:3], 31, 1, 15)[0] * 1.5
+    x[3, :, 100:300, 150:330] = x[3, :, 100:300, 150:330] * 0.3 + 0.5
+    got = net(x.cuda()).cpu()
+    want = MO.model_forward({k: v for k, v in P.items()}, x)
+    S, size = 15, 480
+    ps = size / S
+    n_checked = n_boxes = 0
+    worst = tot = 0.0
+    alld = []
+    for pt in (0.5, float(want[:, 0].quantile(0.9)), float(want[:, 0].quantile(0.5))):
+        sure = (want[:, 0] - pt).abs() > 0.03
+        sel_g, sel_w = got[:, 0] > pt, want[:, 0] > pt
+        assert torch.equal(sel_g[sure], sel_w[sure])
+        n_checked += int(sure.sum())
+        both = sel_g & sel_w
+        ii = torch.arange(S, dtype=torch.float32)[None, :, None].expand(4, S, S)
+        jj = torch.arange(S, dtype=torch.float32)[None, None, :].expand(4, S, S)
+
+        def boxes(m):
+            X = m[:, 1] * ps + ii * ps
+            Y = m[:, 2] * ps + jj * ps
+            return torch.stack([X, Y, m[:, 3] * size + X, m[:, 4] * size + Y], 1).round()
+        d = (boxes(got) - boxes(want)).abs().permute(0, 2, 3, 1)[both]
+        if d.numel():
+            n_boxes += d.shape[0]
+            worst = max(worst, float(d.max()))
+            tot += float(d.sum()) / 4
+            alld.append(d.reshape(-1))
+    print("mobilenet box level: cells checked", n_checked, "boxes compared", n_boxes, "worst |d| px", worst,
+          "mean px", tot / max(n_boxes, 1))
+    assert n_checked > 1000 and n_boxes > 50
+    q99 = float(torch.cat(alld).quantile(0.99))
+    print("   99th percentile px", q99)
+    assert q99 <= 0.03 * size + 1 and worst <= 0.1 * size and tot / max(n_boxes, 1) <= 3.0
+
+
 def test_predict_path_uint8_frames(golden):
     """forward(frames, predict=1): uint8 frames at the model size go straight to the stem (the /255 fused); the result
     equals decode+NMS of the maps from the float path, and frames of another size go through the resize kernel."""

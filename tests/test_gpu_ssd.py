@@ -218,3 +218,42 @@ def test_ssd_loss_parts_of_two_shards_equal_the_whole_batch(hp):
         got = torch.cat([ga, gb])
         assert bool(torch.isfinite(got).all())
         assert torch.allclose(got, grad_ref, rtol=1e-6, atol=1e-9)
+
+
+def test_reference_modelmeta_ssd_validation_step_and_epoch_hooks(golden, tmp_path):
+    """`ModelMetaSSD.validation_step` against the reference's own (tests/golden/g14_modelmeta_ssd.npz, made by
+    tools/make_goldens_r3.py running models/ModelMetaSSD.py:110-231 on the reference SSD): loss and the metric block
+    total_iou / total_recall / total_precision; then the epoch hooks (format_metrics / *_epoch_end, :245-327)."""
+    import fdet_amd
+    from fdet_amd.models.SSD import SSD
+    from fdet_amd.models.ModelMetaSSD import ModelMetaSSD
+    from oracle import ssd_model_oracle as SM
+    g = golden("g14_modelmeta_ssd")
+    fil, seed, size = int(g["filters"]), int(g["seed"]), 480
+    P = SM.init_params(fil, seed)
+    shift = float(g["conf_bias_shift"])
+    for k in str(g["head_bias_names"]).split("|"):
+        P[k] = P[k].clone()
+        P[k][0] += shift
+    model = SSD(filters=fil, input_shape=(3, size, size))
+    model.load_state_dict(P)
+    model = model.cuda().eval()
+    B = g["target"].shape[0]
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    mm = ModelMetaSSD(model=model, lr=1e-4, log_path=tmp_path / "ssd.log")
+    mm.configure_optimizers()
+    with torch.no_grad():
+        y_hat = model(x.cuda())
+        out = mm.validation_step((x.cuda(), g["target"].cuda(), None), 1)
+    # every confidence is on the reference's side of the 0.5 threshold (the fixture records how far the closest one is)
+    assert float((y_hat[:, :, 0].cpu() - g["y_hat"][:, :, 0]).abs().max()) < 0.5 * float(g["threshold_gap"])
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 1e-4 * float(g["loss"])
+    assert abs(float(out["total_iou"]) - float(g["total_iou"])) <= 1e-4 * max(1.0, float(g["total_iou"]))
+    assert float(out["total_recall"]) == float(g["total_recall"])
+    assert float(out["total_precision"]) == float(g["total_precision"])
+    # epoch hooks: validation first (Lightning's order), then the training line that quotes both
+    mm.validation_epoch_end([out, out])
+    m = mm.format_metrics([out], training=True)
+    assert abs(float(m["loss"]) - float(g["loss"])) <= 1e-4 * float(g["loss"]) and "f1_score" in m
+    line = (tmp_path / "ssd.log").read_text()
+    assert "training, loss" in line and "validation, loss" in line
