@@ -645,6 +645,12 @@ k_wgrad3x3_x3_pipe(const WgX3Args a) {
     WGP_STEP(PAR, S, 2, 0, v0n_)                                                                  \
     WGP_STEP(PAR, S, 3, 1, v0n_)                                                                  \
     if (ks0 + 4 < ks1) WGP_STEP(PAR, S, 4, 0, v0n_)                                               \
+    /* retire BOTH register sets before the band ends: no asm-load destination is in flight across the loop back */ \
+    /* edge, where hipcc bridges the two band bodies with register copies (tools/audit_asm_loads.py: 307 touches */ \
+    /* of in-flight destinations before, 0 now).  The loads of band + 3 then have the rest of this band to land  */ \
+    /* instead of two bands: measured cost in DESIGN.md 2.2c.                                                      */ \
+    WGP_WAIT(PAR, 0)                                                                              \
+    WGP_WAIT(S, 0)                                                                                \
     __syncthreads();                                                                              \
     item += 1;                                                                                    \
   }
@@ -797,6 +803,9 @@ WgX3Plan plan_x3(int N, int Cin, int Cout, int H, int W, int L = 1) {
       // rows of 13..16 floats (one-float form, 16 lanes) or 29..32 floats (the 32-lane form): float4 quads instead
       p.pk4 = p.pipe && !(e4 && e4[0] == '0') && ((!p.lpr32 && p.vw == 1 && W >= 13 && W <= 16 && p.P == 16) || (p.lpr32 && W >= 29 && p.P == 32));
     }
+    // the one-float 16-lane form (rows of <= 12 floats, or PK4 switched off) is not built as a pipeline any more: its
+    // asm-load audit is not clean and those maps are tiny -- they take the staged kernel
+    if (p.pipe && p.vw == 1 && !p.lpr32 && !p.pk4) { p.pipe = false; p.lpr32 = false; }
     if (p.pipe) bestR = p.lpr32 ? 4 : rp;      // -> Kext 144, QZ 168, PX 152 + 2 P: the kernel's compile-time geometry
   }
   p.R = bestR;
@@ -825,14 +834,13 @@ int launch_x3(const WgX3Args& a, const WgX3Plan& p, dim3 grid, hipStream_t st) {
 #ifdef FDET_WG_DBG
     const char* e = FDET_ENV_ONCE("FDET_WG_DBG");
     const int dbg = e ? atoi(e) : 0;
-#define WG_DBG_CASE(D) if (dbg == D && !p.lpr32) { if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4, D>); else go(k_wgrad3x3_x3_pipe<1, D>); return rc; }
+#define WG_DBG_CASE(D) if (dbg == D && !p.lpr32 && p.vw == 4) { go(k_wgrad3x3_x3_pipe<4, D>); return rc; }
     WG_DBG_CASE(1) WG_DBG_CASE(3) WG_DBG_CASE(8) WG_DBG_CASE(9) WG_DBG_CASE(24) WG_DBG_CASE(40) WG_DBG_CASE(73)
 #endif
     if (p.lpr32 && p.pk4) go(k_wgrad3x3_x3_pipe<4, 0, 32, 1>);
     else if (p.lpr32) go(k_wgrad3x3_x3_pipe<1, 0, 32>);
     else if (p.pk4) go(k_wgrad3x3_x3_pipe<4, 0, 16, 1>);
-    else if (p.vw == 4) go(k_wgrad3x3_x3_pipe<4>);
-    else go(k_wgrad3x3_x3_pipe<1>);
+    else go(k_wgrad3x3_x3_pipe<4>);                     // p.vw == 4 (plan_x3 routes the one-float 16-lane form to the staged kernel)
   } else if (p.NSEG > 1) go(k_wgrad3x3_x3<MTC, 4, true>);
   else if (p.pack) go(k_wgrad3x3_x3<MTC, 4, false, true>);
   else if (p.vw == 4) go(k_wgrad3x3_x3<MTC, 4, false>);
