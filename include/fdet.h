@@ -264,6 +264,22 @@ int fdet_block_chain_bwd_bf16x3(const float* dout, const void* const* h_wpk1b, c
                                 float* const* h_dz1, float* const* h_dz2, float* dx, int nblocks, int N, int F,
                                 int H, int W, float slope, void* stream);
 
+/* The same chain with the tensors kept per block in the engine's PS layout (csrc/fdet_ps.h; PS image-0 pointers):
+ *   forward : h_a_ps[k] (both planes) and h_out_ps[k], k < nblocks-1 (both planes) are operands of the weight gradients,
+ *             h_c_ps[k] receives the hi plane only (backward needs the signs of c_k); arrays or entries may be NULL
+ *             (not kept).  The last block's output is written to out_last as fp32 NCHW.  x: fp32 NCHW, or PS if x_is_ps.
+ *   backward: dout, dx fp32 NCHW; h_dz1_ps / h_dz2_ps are written as PS.
+ * No reference counterpart beyond the one of fdet_block_chain_*_bf16x3; values are identical to that flavour's
+ * (a PS element is the fp32 value rounded to its bf16 hi + lo parts, which is all the bf16x3 consumers read). */
+int fdet_block_chain_fwd_ps(const void* x, int x_is_ps, const void* const* h_wpk1, const float* const* h_b1,
+                            const void* const* h_wpk2, const float* const* h_b2, const float* const* h_scale,
+                            void* const* h_a_ps, void* const* h_c_ps, void* const* h_out_ps, float* out_last,
+                            int nblocks, int N, int F, int H, int W, float slope, void* stream);
+int fdet_block_chain_bwd_ps(const float* dout, const void* const* h_wpk1b, const void* const* h_wpk2b,
+                            const float* const* h_scale, const void* const* h_a_ps, const void* const* h_c_ps,
+                            void* const* h_dz1_ps, void* const* h_dz2_ps, float* dx, int nblocks, int N, int F,
+                            int H, int W, float slope, void* stream);
+
 /* Residual-block tail for pooled blocks: out = maxpool_pool(c*drop_scale[n,f] + x)
  * (Dropout2d + skip add + MaxPool2d(2), models/PoolResnet.py:39-42).  pool in {1,2}.
  *   c,x [N,F,H,W]; drop_scale [N,F] or NULL; out [N,F,H/pool,W/pool] (floor: an odd last row/column is dropped). */

@@ -107,6 +107,8 @@ SIGNATURES = {
     "fdet_block_chain_supported": (_I, [_I, _I, _I]),
     "fdet_block_chain_fwd_bf16x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_block_chain_bwd_bf16x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_block_chain_fwd_ps": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_block_chain_bwd_ps": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_block_tail_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fdet_block_tail_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_stem_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I, _I, _I]),

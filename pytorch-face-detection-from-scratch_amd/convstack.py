@@ -219,6 +219,14 @@ class ConvStack:
         hk, pool = self.lv[k]
         return pool == 2 and hk % 2 == 0 and 30 <= hk <= 62 and self._fused_pool(hk)
 
+    def _ps_chain(self, k: int) -> bool:
+        """The chain run starting at block k keeps its per-block tensors in PS (fdet_block_chain_*_ps) and its weight
+        gradients come from the PS kernel."""
+        if not self.ps or k >= len(self.lv) or self._chain_run(k) <= 1:
+            return False
+        hk = self.lv[k][0]
+        return psm.conv3x3_wgrad_ps_ws_bytes(1, 1, self.geo.filters, hk, hk) > 0
+
     def _ps_take(self, scope: "_PsScope", N: int, C: int, H: int, W: int, dev) -> "psm.PsTensor":
         """A zero-haloed PS buffer from the engine's pool; it returns to the pool when `scope` (kept alive by the saved
         state of a forward pass, or released at the end of an inference call) goes away.  Producers write real elements
@@ -284,7 +292,7 @@ class ConvStack:
                 a_ps = self._ps_take(scope, N, F_, hk, hk, dev)
                 with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2)):
                     psm.conv3x3_ps_fwd(h_ps, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], a_ps, self.slope)
-                nxt = self._ps_block(k + 1)
+                nxt = self._ps_block(k + 1) or self._ps_chain(k + 1)
                 out_ps = self._ps_take(scope, N, F_, hk // 2, hk // 2, dev) if nxt else None
                 out = None if nxt else torch.empty(N, F_, hk // 2, hk // 2, dtype=F32, device=dev)
                 route = psm.route8_like(N, F_, hk, hk, dev) if save else None
@@ -296,8 +304,28 @@ class ConvStack:
                 h, h_ps = out, out_ps
                 continue
             run = self._chain_run(k)
+            if run > 1 and self._ps_chain(k):
+                # blocks k .. k+run-1 keep their activation on the CU: one launch (fdet_block_chain_fwd_ps); what backward
+                # needs is kept in PS (a_k, block outputs: operands of the weight gradients; c_k: hi plane = its signs)
+                names = [f"residual_blocks.{kk}" for kk in range(k, k + run)]
+                if h_ps is None:
+                    h_ps = psm.PsTensor.from_f32(h, out=self._ps_take(scope, N, F_, hk, hk, dev))
+                a_l = [self._ps_take(scope, N, F_, hk, hk, dev) for _ in names] if save else None
+                c_l = [self._ps_take(scope, N, F_, hk, hk, dev) for _ in names] if save else None
+                o_l = [self._ps_take(scope, N, F_, hk, hk, dev) for _ in names[:-1]] if save else None
+                out = torch.empty(N, F_, hk, hk, dtype=F32, device=dev)
+                with self._t("chain_fwd", N, hk, 2 * run * self._conv_flops(N, hk), self._act_bytes(N, hk, 1 + (2.5 * run if save else 1))):
+                    psm.block_chain_fwd_ps(h_ps, [self._wpk[nm + ".conv1.f"] for nm in names], [P[nm + ".conv1.bias"] for nm in names],
+                                           [self._wpk[nm + ".conv2.f"] for nm in names], [P[nm + ".conv2.bias"] for nm in names],
+                                           [masks[nm] for nm in names] if masks is not None else None, a_l, c_l, o_l, out, self.slope)
+                if save:
+                    for i in range(run):
+                        saved["blocks"].append((h_ps if i == 0 else o_l[i - 1], a_l[i], c_l[i]))
+                h, h_ps = out, None
+                k += run - 1
+                continue
             if run > 1:
-                # blocks k .. k+run-1 keep their activation on the CU: one launch (fdet_block_chain_fwd_bf16x3)
+                # the same with fp32 NCHW tensors (fdet_block_chain_fwd_bf16x3)
                 names = [f"residual_blocks.{kk}" for kk in range(k, k + run)]
                 a_l = [torch.empty(N, F_, hk, hk, dtype=F32, device=dev) for _ in names] if save else None
                 c_l = [torch.empty(N, F_, hk, hk, dtype=F32, device=dev) for _ in names] if save else None
@@ -430,6 +458,39 @@ class ConvStack:
         while k > 0:
             k -= 1
             hk, pool = self.lv[k]
+            if k in chain_start and self._ps_chain(chain_start[k]):
+                k0 = chain_start[k]
+                ks = list(range(k0, k + 1))
+                names = [f"residual_blocks.{q}" for q in ks]
+                scope = saved.get("ps_scope")
+                if scope is None:
+                    scope = saved["ps_scope"] = _PsScope(self._ps_pool)
+
+                def as_ps(t):                             # (a caller may have replaced saved tensors by fp32 NCHW ones)
+                    if isinstance(t, psm.PsTensor):
+                        return t
+                    return psm.PsTensor.from_f32(t.to(F32).contiguous(), out=self._ps_take(scope, N, F_, hk, hk, dev))
+                x_l = [as_ps(saved["blocks"][q][0]) for q in ks]
+                a_l = [as_ps(saved["blocks"][q][1]) for q in ks]
+                c_l = [as_ps(saved["blocks"][q][2]) for q in ks]
+                dz1_l = [self._ps_take(scope, N, F_, hk, hk, dev) for _ in ks]
+                dz2_l = [self._ps_take(scope, N, F_, hk, hk, dev) for _ in ks]
+                dx = torch.empty_like(dout)
+                with self._t("chain_bwd", N, hk, 2 * len(ks) * self._conv_flops(N, hk), self._act_bytes(N, hk, 2 + 3 * len(ks))):
+                    psm.block_chain_bwd_ps(dout, [self._wpk[nm + ".conv1.b"] for nm in names], [self._wpk[nm + ".conv2.b"] for nm in names],
+                                           [masks[nm] for nm in names] if masks is not None else None, a_l, c_l, dz1_l, dz2_l, dx, self.slope)
+                for i in reversed(range(len(ks))):
+                    pending_ps.append((a_l[i], dz2_l[i], names[i] + ".conv2"))
+                    pending_ps.append((x_l[i], dz1_l[i], names[i] + ".conv1"))
+                dout = dx
+                k = k0
+                if k == 0 or self.lv[k - 1][0] != hk:
+                    flush_ps(hk)
+                    if after_block is not None:
+                        for q in range(k, g.num_blocks):
+                            if self.lv[q][0] == hk:
+                                after_block(q)
+                continue
             if k in chain_start:
                 k0 = chain_start[k]
                 ks = list(range(k0, k + 1))

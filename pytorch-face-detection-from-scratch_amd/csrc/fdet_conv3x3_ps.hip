@@ -555,7 +555,7 @@ int run_ps(int mode, const void* x, const void* wpk, const float* bias, const vo
   const bool pooled = mode == PSE_FWD_POOL || mode == PSE_DGRAD_ADDPOOL;
   FDET_REQUIRE(x && wpk && (y || pooled), "conv3x3_ps: null pointer");
   FDET_REQUIRE(Cout == 64 && Cin % 16 == 0 && Cin >= 32, "conv3x3_ps: Cout must be 64 and Cin a multiple of 16 (Cin=%d Cout=%d)", Cin, Cout);
-  FDET_REQUIRE(ps_geo(N, Cin, H, W, gi) && ps_geo(N, Cout, H, W, go) && gi.WP >= 32, "conv3x3_ps: unsupported map %dx%d", H, W);
+  FDET_REQUIRE(ps_geo(N, Cin, H, W, gi) && ps_geo(N, Cout, H, W, go) && gi.WP >= 32 && W + 2 <= gi.WP, "conv3x3_ps: unsupported map %dx%d (W + 2 <= 32 or 64 slots)", H, W);
   FDET_REQUIRE(slope >= 0.f && slope <= 1.f, "conv3x3_ps: slope must be in [0, 1]");
   PsConvArgs p;
   p.x = reinterpret_cast<const bf16x8*>(x);

@@ -6,10 +6,11 @@
 //   unit (16 bytes = 8 bf16) index of image n, plane pl (0 = hi, 1 = lo), channel group g = c / 8, row y, slot s
 //       n * img + pl * plane + (g * HP + y) * WP + s          plane = (C/8) * HP * WP,  img = 2 * plane
 //
-//   * slot s = x + 1: slot 0 and slots W+1 .. WP-1 of every row are ZERO (left / right halo); WP = 16 / 32 / 64;
-//   * rows y = H .. HP-1 are ZERO (HP = H + 2 rounded up to even): the row under an image and the row above the next
-//     one, so a band of "virtual rows" v = n * HP + y may run across images and a row pair (v, v+1) with v even
-//     is a row pair (y, y+1) with y even of one image;
+//   * slot s = x + 1: slot 0 and slots W+1 .. WP-1 of every row are ZERO; WP = 16 / 32 / 64 >= W + 1.  Slot 0 is the
+//     left halo of its row AND (read as "slot WP" of the row above) the right halo of that one, so W = WP - 1 is fine;
+//   * rows y = H .. HP-1 are ZERO (HP = H + 1 rounded up to even): one row is both the halo under an image and the
+//     halo above the next one, so a band of "virtual rows" v = n * HP + y may run across images, and a row pair
+//     (v, v+1) with v even is a row pair (y, y+1) with y even of one image;
 //   * the buffer holds one all-zero guard image in front of image 0 and one behind image N-1 (virtual rows -1 and
 //     N*HP .. of the first / last band); producers write real elements only, the zeros are written once at
 //     allocation (fdet_ps_bytes / fdet_ps_image0_offset describe the allocation).
@@ -28,12 +29,12 @@ struct PsGeo {
   int plane, img;          // 16-byte units
 };
 
-inline int ps_wp(int W) { return W + 2 <= 16 ? 16 : (W + 2 <= 32 ? 32 : (W + 2 <= 64 ? 64 : 0)); }
+inline int ps_wp(int W) { return W + 1 <= 16 ? 16 : (W + 1 <= 32 ? 32 : (W + 1 <= 64 ? 64 : 0)); }
 
 inline bool ps_geo(int N, int C, int H, int W, PsGeo& g) {
   g.N = N; g.C = C; g.H = H; g.W = W;
   g.WP = ps_wp(W);
-  g.HP = (H + 3) & ~1;
+  g.HP = (H + 2) & ~1;
   g.C8 = C / 8;
   if (g.WP == 0 || C % 8 != 0 || N < 1 || H < 1) return false;
   const long long plane = (long long)g.C8 * g.HP * g.WP;

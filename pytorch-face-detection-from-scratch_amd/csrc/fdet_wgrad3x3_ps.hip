@@ -298,7 +298,7 @@ int wg_num_cus() {
 }
 
 int wg_plan(int L, int N, int H, int W, PsGeo& g, int& nslab, int& lpw) {
-  if (!ps_geo(N, 64, H, W, g) || g.WP < 32 || L < 1 || L > WG_MAXL) return 0;
+  if (!ps_geo(N, 64, H, W, g) || L < 1 || L > WG_MAXL) return 0;
   const int lpi = g.HP * g.WP / 64;
   const long nlines = (long)N * lpi;
   if (nlines + 2 * lpi >= (1 << 20)) return 0;
@@ -359,9 +359,10 @@ extern "C" int fdet_conv3x3_wgrad_ps_batched(const void* const* h_x, const void*
     hipLaunchKernelGGL(kern, dim3(nslab, L), dim3(256), lds, st, a);
     return FDET_OK;
   };
-  static bool d64a = false, d64b = false, d32a = false, d32b = false;
+  static bool d64a = false, d64b = false, d32a = false, d32b = false, d16a = false, d16b = false;
   int rc0;
   if (g.WP == 64) rc0 = fl1 ? go(k_wgrad3x3_ps<64, true>, d64a) : go(k_wgrad3x3_ps<64, false>, d64b);
+  else if (g.WP == 16) rc0 = fl1 ? go(k_wgrad3x3_ps<16, true>, d16a) : go(k_wgrad3x3_ps<16, false>, d16b);
   else rc0 = fl1 ? go(k_wgrad3x3_ps<32, true>, d32a) : go(k_wgrad3x3_ps<32, false>, d32b);
   if (rc0 != FDET_OK) return rc0;
   int rc = check_launch("fdet_conv3x3_wgrad_ps_batched");

@@ -161,3 +161,57 @@ def stem_fwd_ps(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, y: PsTenso
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     _same(y, (N, F_, Ho, Wo), "stem_fwd_ps: y")
     check(lib().fdet_stem_fwd_ps(ptr(x), ptr(w), ptr(bias), y.data, N, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_fwd_ps")
+
+
+def _ps_ptr_array(ts):
+    """HOST array of PS image-0 pointers (None entries -> NULL); None -> NULL array."""
+    import ctypes
+    if ts is None:
+        return None
+    return (ctypes.c_void_p * len(ts))(*[(t.data if t is not None else None) for t in ts])
+
+
+def block_chain_fwd_ps(x, wpk1, b1, wpk2, b2, scales, a_ps, c_ps, out_ps, out_last: torch.Tensor, slope: float = 0.2) -> None:
+    """The LDS-resident residual-block chain (fdet_block_chain_fwd_ps) keeping a_k / c_k / block outputs as PS tensors.
+    x: PsTensor or fp32 NCHW; a_ps, c_ps: lists of nblocks PsTensors (or None: not kept); out_ps: nblocks-1 PsTensors
+    (or None); out_last: fp32 NCHW output of the last block.  c_ps[k] only receives its hi plane (its signs)."""
+    from .hotpath import _ptr_array
+    nb = len(wpk1)
+    N, C, H, W = out_last.shape
+    x_is_ps = isinstance(x, PsTensor)
+    if x_is_ps:
+        _same(x, (N, C, H, W), "block_chain_fwd_ps: x")
+    elif tuple(x.shape) != (N, C, H, W) or x.dtype != F32 or not x.is_contiguous():
+        raise ValueError("block_chain_fwd_ps: x must be a PsTensor or a contiguous fp32 tensor of the output's shape")
+    if not (len(b1) == len(wpk2) == len(b2) == nb) or (scales is not None and len(scales) != nb):
+        raise ValueError("block_chain_fwd_ps: inconsistent per-block lists")
+    for lst, n_, nm in ((a_ps, nb, "a"), (c_ps, nb, "c"), (out_ps, nb - 1, "out")):
+        if lst is not None:
+            if len(lst) != n_:
+                raise ValueError(f"block_chain_fwd_ps: {nm} needs {n_} entries")
+            for t in lst:
+                if t is not None:
+                    _same(t, (N, C, H, W), "block_chain_fwd_ps: " + nm)
+    check(lib().fdet_block_chain_fwd_ps(x.data if x_is_ps else ptr(x), int(x_is_ps), _ptr_array(wpk1), _ptr_array(b1),
+                                        _ptr_array(wpk2), _ptr_array(b2), _ptr_array(scales), _ps_ptr_array(a_ps),
+                                        _ps_ptr_array(c_ps), _ps_ptr_array(out_ps), ptr(out_last), nb, N, C, H, W,
+                                        float(slope), stream()), "fdet_block_chain_fwd_ps")
+
+
+def block_chain_bwd_ps(dout: torch.Tensor, wpk1b, wpk2b, scales, a_ps, c_ps, dz1_ps, dz2_ps, dx: torch.Tensor,
+                       slope: float = 0.2) -> None:
+    """Data-gradient chain of the same blocks (fdet_block_chain_bwd_ps): fills dz1_ps[k], dz2_ps[k] (PS) and dx (fp32)."""
+    from .hotpath import _ptr_array
+    nb = len(wpk1b)
+    N, C, H, W = dout.shape
+    if not (len(wpk2b) == len(a_ps) == len(c_ps) == len(dz1_ps) == len(dz2_ps) == nb):
+        raise ValueError("block_chain_bwd_ps: inconsistent per-block lists")
+    for lst, nm in ((a_ps, "a"), (c_ps, "c"), (dz1_ps, "dz1"), (dz2_ps, "dz2")):
+        for t in lst:
+            _same(t, (N, C, H, W), "block_chain_bwd_ps: " + nm)
+    if tuple(dx.shape) != (N, C, H, W):
+        raise ValueError("block_chain_bwd_ps: dx shape mismatch")
+    check(lib().fdet_block_chain_bwd_ps(ptr(dout), _ptr_array(wpk1b), _ptr_array(wpk2b), _ptr_array(scales),
+                                        _ps_ptr_array(a_ps), _ps_ptr_array(c_ps), _ps_ptr_array(dz1_ps),
+                                        _ps_ptr_array(dz2_ps), ptr(dx), nb, N, C, H, W, float(slope), stream()),
+          "fdet_block_chain_bwd_ps")

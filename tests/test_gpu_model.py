@@ -387,6 +387,8 @@ def test_gradient_entries_differ_only_through_pool_routing(fd):
             xin, a, third = saved["blocks"][k]
             if hasattr(a, "to_f32"):                         # pre-split (PS) path: bf16 hi|lo activation, channel-innermost routing bytes
                 a = a.to_f32()
+            if hasattr(third, "to_f32"):                     # chain blocks keep c's hi plane only: its signs are what backward reads
+                third = third.to_f32()
             if third.dtype == torch.uint8 and third.dim() == 5:
                 n_, g_, hp_, wp_, _ = third.shape
                 third = third.permute(0, 1, 4, 2, 3).reshape(n_, g_ * 8, hp_, wp_)

@@ -77,7 +77,7 @@ def test_conv3x3_ps_fwd_and_dgrad(env, shape):
     close(dxp.to_f32(), ref)
 
 
-@pytest.mark.parametrize("shape", PS_SHAPES)
+@pytest.mark.parametrize("shape", PS_SHAPES + [(3, 64, 15, 15), (4, 64, 10, 10), (2, 64, 5, 31)])
 @pytest.mark.parametrize("L", [1, 2])
 def test_conv3x3_wgrad_ps(env, shape, L):
     hp, ps = env
@@ -188,3 +188,96 @@ def test_stem_fwd_ps(env, N):
     close(y.to_f32(), ref)
     real = ps.PsTensor.from_f32(torch.full((N, 64, 60, 60), 1.0 + 2.0 ** -9, device="cuda"))
     assert int((y.buf.view(torch.int16)[real.buf.view(torch.int16) == 0] != 0).sum()) == 0
+
+
+@pytest.mark.parametrize("cfg", [(3, 15, 15, 3, True), (2, 10, 10, 2, False), (5, 15, 15, 8, True), (1, 7, 9, 1, True)])
+def test_block_chain_ps_flavour(env, cfg):
+    """The LDS-resident block chain keeping its per-block tensors in PS (fdet_block_chain_{fwd,bwd}_ps) against torch CPU
+    fp32 of models/PoolResnet.py:33-43 (pool == 1) and its autograd, and against the fp32-NCHW flavour of the same kernel:
+    the chain output and input gradient are bit-identical, a kept PS tensor is the fp32 one rounded to hi + lo."""
+    hp, ps = env
+    N, H, W, nb, use_scale = cfg
+    C = 64
+    g = torch.Generator().manual_seed(N * 100 + H + nb)
+    x = torch.randn(N, C, H, W, generator=g)
+    Ws = [(torch.randn(C, C, 3, 3, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1,
+           torch.randn(C, C, 3, 3, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1) for _ in range(nb)]
+    scales = [((torch.rand(N, C, generator=g) > 0.25).float() / 0.75) for _ in range(nb)] if use_scale else None
+    x_ps = ps.PsTensor.from_f32(x.cuda())
+    xq = x_ps.to_f32()                                      # the input as PS holds it
+    xr = xq.cpu().clone().requires_grad_(True)
+    h = xr
+    a_ref, c_ref, o_ref, z1, z2 = [], [], [], [], []
+    for k in range(nb):
+        w1, b1, w2, b2 = Ws[k]
+        p1 = F.conv2d(h, w1, b1, padding=1); p1.retain_grad(); z1.append(p1)
+        a = F.leaky_relu(p1, 0.2)
+        p2 = F.conv2d(a, w2, b2, padding=1); p2.retain_grad(); z2.append(p2)
+        c = F.leaky_relu(p2, 0.2)
+        h = (c * scales[k][:, :, None, None] if use_scale else c) + h
+        a_ref.append(a.detach()); c_ref.append(c.detach()); o_ref.append(h.detach())
+    dout = torch.randn(N, C, H, W, generator=g)
+    h.backward(dout)
+    nf, nbk = hp.packed_sizes(C, C)
+    wf1, wb1, wf2, wb2 = [], [], [], []
+    for (w1, b1, w2, b2) in Ws:
+        for w, lf, lb in ((w1, wf1, wb1), (w2, wf2, wb2)):
+            f_ = torch.empty(nf, device="cuda"); b_ = torch.empty(nbk, device="cuda")
+            hp.pack_conv3x3_weights(w.cuda(), f_, b_, x3=True)
+            lf.append(f_); lb.append(b_)
+    b1s = [w[1].cuda() for w in Ws]; b2s = [w[3].cuda() for w in Ws]
+    sc_d = [s_.cuda() for s_ in scales] if use_scale else None
+    mkps = lambda n_: [ps.PsTensor(N, C, H, W, "cuda") for _ in range(n_)]
+    mk = lambda: [torch.full((N, C, H, W), float("nan"), device="cuda") for _ in range(nb)]
+    # fp32 flavour on the same input
+    a_d, c_d, o_d = mk(), mk(), mk()
+    hp.block_chain_fwd(xq, wf1, b1s, wf2, b2s, sc_d, a_d, c_d, o_d)
+    for x_in in (x_ps, xq):                                  # PS input, fp32 input
+        a_p, c_p, o_p = mkps(nb), mkps(nb), mkps(nb - 1)
+        last = torch.full((N, C, H, W), float("nan"), device="cuda")
+        ps.block_chain_fwd_ps(x_in, wf1, b1s, wf2, b2s, sc_d, a_p, c_p, o_p, last)
+        assert torch.equal(last, o_d[-1])
+        close(last, o_ref[-1])
+        for k in range(nb):
+            close(a_p[k].to_f32(), a_ref[k])
+            assert torch.equal(a_p[k].to_f32(), ps.PsTensor.from_f32(a_d[k]).to_f32())
+            chi = c_p[k].to_f32().cpu()                      # hi plane only
+            firm = c_ref[k].abs() > 1e-3 * max(1.0, float(c_ref[k].abs().max()))
+            assert torch.equal((chi > 0)[firm], (c_ref[k] > 0)[firm])
+            assert torch.equal(chi > 0, c_d[k].cpu() > 0)
+            if k + 1 < nb:
+                close(o_p[k].to_f32(), o_ref[k])
+                assert torch.equal(o_p[k].to_f32(), ps.PsTensor.from_f32(o_d[k]).to_f32())
+        # nothing outside the real elements was written
+        real = ps.PsTensor.from_f32(torch.full((N, C, H, W), 1.0 + 2.0 ** -9, device="cuda"))
+        outside = real.buf.view(torch.int16) == 0
+        for t in a_p + c_p + o_p:
+            assert int((t.buf.view(torch.int16)[outside] != 0).sum()) == 0
+    # inference flavour: nothing kept
+    last2 = torch.full((N, C, H, W), float("nan"), device="cuda")
+    ps.block_chain_fwd_ps(x_ps, wf1, b1s, wf2, b2s, sc_d, None, None, None, last2)
+    assert torch.equal(last2, o_d[-1])
+    # backward, fp32 dout and dx.  The kept activations are the REFERENCE's here (as in test_block_chain_fwd_bwd): a
+    # device-computed a / c within 1e-4 of zero may carry the other sign, and one flipped LeakyReLU' is a visible gradient
+    # difference that says nothing about the backward kernel.
+    a_t = [ps.PsTensor.from_f32(t.cuda()) for t in a_ref]; c_t = [ps.PsTensor.from_f32(t.cuda()) for t in c_ref]
+    dz1_p, dz2_p = mkps(nb), mkps(nb)
+    dx_p = torch.full((N, C, H, W), float("nan"), device="cuda")
+    ps.block_chain_bwd_ps(dout.cuda(), wb1, wb2, sc_d, a_t, c_t, dz1_p, dz2_p, dx_p)
+    dz1_d, dz2_d = mk(), mk()
+    dx_d = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.block_chain_bwd(dout.cuda(), wb1, wb2, sc_d, [t.cuda() for t in a_ref], [t.cuda() for t in c_ref], dz1_d, dz2_d, dx_d)
+    # ... and with the PS tensors the forward kept: the two flavours agree bit for bit on those as well
+    dz1_q, dz2_q = mkps(nb), mkps(nb)
+    dx_q = torch.full((N, C, H, W), float("nan"), device="cuda")
+    ps.block_chain_bwd_ps(dout.cuda(), wb1, wb2, sc_d, a_p, c_p, dz1_q, dz2_q, dx_q)
+    dx_e = torch.full((N, C, H, W), float("nan"), device="cuda")
+    hp.block_chain_bwd(dout.cuda(), wb1, wb2, sc_d, a_d, c_d, mk(), mk(), dx_e)
+    assert torch.equal(dx_q, dx_e)
+    assert torch.equal(dx_p, dx_d)
+    close(dx_p, xr.grad)
+    for k in range(nb):
+        close(dz1_p[k].to_f32(), z1[k].grad)
+        close(dz2_p[k].to_f32(), z2[k].grad)
+        assert torch.equal(dz1_p[k].to_f32(), ps.PsTensor.from_f32(dz1_d[k]).to_f32())
+        assert torch.equal(dz2_p[k].to_f32(), ps.PsTensor.from_f32(dz2_d[k]).to_f32())
