@@ -93,6 +93,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // (an element of an ext-vector is copied to a scalar before any bit cast: see fdet_wgrad3x3_ps.hip)
 __device__ __forceinline__ unsigned ch_elem(const u32x2& v, int k) { return k ? v.y : v.x; }
 
+// PS = the per-block tensors are PS (ChainArgs::psio bit 0): that instantiation carries no fp32 tile of the kept
+// activation, and spends the registers on the NEXT layer's bias (the accumulators start from it) and this layer's
+// dropout scales, both loaded a layer ahead of their use
+template <bool PS>
 __global__ void __launch_bounds__(NTHR, 1)
 k_block_chain_x3(const ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -297,11 +301,21 @@ k_block_chain_x3(const ChainArgs a) {
         _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) DST[m_][r_] = 1.f;                       \
     }                                                                                              \
   }
+  // the same from a per-channel vector, four consecutive channels per load
+#define CH_VEC_TILE(DST, PTR)                                                                      \
+  {                                                                                                \
+    const float* __restrict__ p_ = (PTR);                                                          \
+    _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                               \
+      _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                           \
+        const f32x4 v_ = *reinterpret_cast<const f32x4*>(p_ + 32 * m_ + 8 * g_ + 4 * half);       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) DST[m_][4 * g_ + i_] = v_[i_];            \
+      }                                                                                            \
+  }
 #define CH_FOR_ALL _Pragma("unroll") for (int j = 0; j < NT; ++j) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int r = 0; r < 16; ++r)
   f32x16 Hreg[NT][2];                                           // skip connection / running gradient
   f32x16 aux[NT][2];                                            // prefetched lrelu' operand (bwd)
   u32x2 auxb[NT][2][4];                                         // the same as raw PS hi pieces
-  const bool ps = a.psio & 1;
+  constexpr bool ps = PS;
   if (a.psio & 2) CH_LOAD_PS(Hreg, a.in) else CH_LOAD_TILE(Hreg, a.in)
   if (a.bwd) { if (ps) CH_LOAD_HI(auxb, a.pre_ld) else CH_LOAD_TILE(aux, a.pre_ld) }
   __syncthreads();                                              // zero fill done
@@ -352,11 +366,25 @@ k_block_chain_x3(const ChainArgs a) {
   const int w_off = half * FCH + l31;                           // + tap*2*64 + m*32 ; lo: + A_UNITS
   const int x_off = half * PT + wid * (32 * NT) + l31;          // + j*32 + (c16*2 + hl)*2*PT + tapoff
 
+  f32x16 bnext[2], s2p[2];                                      // PS: bias of the layer about to run; scales of this layer
+  if (ps && !a.bwd) CH_VEC_TILE(bnext, a.bias[0])
   int stage = 0;
   for (int L = 0; L < a.nlayers; ++L) {
     f32x16 acc[NT][2];
-    CH_FOR_ALL acc[j][m][r] = 0.f;
     const bool odd = L & 1;
+    if (ps && !a.bwd) {
+      CH_FOR_ALL acc[j][m][r] = bnext[m][r];
+      if (L + 1 < a.nlayers) CH_VEC_TILE(bnext, a.bias[L + 1])
+    } else if (!a.bwd) {                                        // fp32 flavour: the same sum order (bias first), loaded here
+      f32x16 b0[2];
+      CH_VEC_TILE(b0, a.bias[L])
+      CH_FOR_ALL acc[j][m][r] = b0[m][r];
+    } else {
+      CH_FOR_ALL acc[j][m][r] = 0.f;
+    }
+    if (ps && odd) {
+      if (a.sc[L]) { CH_VEC_TILE(s2p, a.sc[L] + n * FCH) } else { _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int r = 0; r < 16; ++r) s2p[m][r] = 1.f; }
+    }
     // the lrelu' operand of this layer's epilogue travels while the MFMAs run
     if (a.bwd && a.ld[L]) {
       if (ps) { CH_LOAD_HI(auxb, a.ld[L]) young += ps_ops; } else { CH_LOAD_TILE(aux, a.ld[L]) young += tile_ops; }
@@ -417,18 +445,14 @@ k_block_chain_x3(const ChainArgs a) {
     // ---- epilogue: every wave is past its last read of X, so X can be overwritten in place
     const bool last = L + 1 == a.nlayers;
     if (!a.bwd) {
-      const float* __restrict__ bias = a.bias[L];
-      CH_FOR_ALL {
-        const float t = acc[j][m][r] + bias[CH_OF(m, r)];
-        acc[j][m][r] = t > 0.f ? t : t * a.slope;
-      }
+      CH_FOR_ALL { const float t = acc[j][m][r]; acc[j][m][r] = t > 0.f ? t : t * a.slope; }   // (the sums started from the bias)
       if (!odd) {                                               // a: next layer's input, kept for backward
         if (ps) { CH_WRITE_X_PS(acc, a.st[L]) young += a.st[L] ? 2 * ps_ops : 0; }
         else { if (a.st[L]) { CH_STORE_TILE(a.st[L], acc) young += tile_ops; } CH_WRITE_X(acc) }
       } else {                                                  // c (kept: fp32, or only its hi part = its signs), block output
         if (a.st[L]) { if (ps) { CH_STORE_HI(acc, a.st[L]) young += ps_ops; } else { CH_STORE_TILE(a.st[L], acc) young += tile_ops; } }
         f32x16 s2[2];
-        CH_SCALE_TILE(s2, a.sc[L])
+        if (ps) { s2[0] = s2p[0]; s2[1] = s2p[1]; } else CH_SCALE_TILE(s2, a.sc[L])
         CH_FOR_ALL Hreg[j][m][r] = acc[j][m][r] * s2[m][r] + Hreg[j][m][r];
         if (ps && !last) { CH_WRITE_X_PS(Hreg, a.st2[L]) young += a.st2[L] ? 2 * ps_ops : 0; }
         else {
@@ -452,7 +476,7 @@ k_block_chain_x3(const ChainArgs a) {
         CH_FOR_ALL Hreg[j][m][r] += acc[j][m][r];
         if (!last) {                                            // dz2 of the next block to run
           f32x16 s2[2];
-          CH_SCALE_TILE(s2, a.sc[L])
+          if (ps) { s2[0] = s2p[0]; s2[1] = s2p[1]; } else CH_SCALE_TILE(s2, a.sc[L])
           if (ps) {
             CH_FOR_ALL acc[j][m][r] = Hreg[j][m][r] * s2[m][r] * (CH_POS(auxb, j, m, r) ? 1.f : a.slope);
             CH_WRITE_X_PS(acc, a.st2[L])
@@ -488,8 +512,13 @@ int launch_chain(ChainArgs& a, hipStream_t st) {
     return fail(FDET_EINVAL, "block_chain_bf16x3: unsupported map %dx%d (needs 64 channels and H*roundup4(W+1) <= 256)", a.H, a.W);
   if ((size_t)a.N * FCH * a.H * a.W >= ((size_t)1 << 31)) return fail(FDET_EINVAL, "block_chain_bf16x3: tensor too large");
   { const char* e_ = FDET_ENV_ONCE("FDET_CHAIN_STAGGER"); a.stagger = e_ ? atoi(e_) : 0; }
-  { if (int rc_ = set_lds_attr((const void*)k_block_chain_x3, (size_t)(lds), __func__)) return rc_; }
-  hipLaunchKernelGGL(k_block_chain_x3, dim3(a.N), dim3(NTHR), lds, st, a);
+  if (a.psio & 1) {
+    { if (int rc_ = set_lds_attr((const void*)k_block_chain_x3<true>, (size_t)(lds), __func__)) return rc_; }
+    hipLaunchKernelGGL(k_block_chain_x3<true>, dim3(a.N), dim3(NTHR), lds, st, a);
+  } else {
+    { if (int rc_ = set_lds_attr((const void*)k_block_chain_x3<false>, (size_t)(lds), __func__)) return rc_; }
+    hipLaunchKernelGGL(k_block_chain_x3<false>, dim3(a.N), dim3(NTHR), lds, st, a);
+  }
   return check_launch("fdet_block_chain_bf16x3");
 }
 

@@ -49,7 +49,10 @@ def test_two_ranks_fused_train_step_equals_single_process(tmp_path, live_dropout
         assert abs(a - b) <= 1e-5 * abs(b), (got["loss_sum"], losses)
     g_ref, g_got = grad, got["grad"]
     gmax = float(g_ref.abs().max())
-    assert float((g_got - g_ref).abs().max()) <= 2e-5 * gmax            # last step's all-reduced flat gradient
+    # last step's all-reduced flat gradient, at the north star's 1e-4: the two runs sum the images in a different order
+    # (2 + 2 and an all-reduce vs 4), and step 2 starts from parameters that already differ where Adam's first update
+    # flipped on a ~0 gradient (below)
+    assert float((g_got - g_ref).abs().max()) <= 1e-4 * gmax
     lr = 1e-4
     for k, p_ref in params.items():
         p_got = got["params"][k]
