@@ -40,7 +40,15 @@ STEP_GFLOP_PER_IMAGE_F64 = 3.0703
 FWD_MB_PER_IMAGE_F64 = 11.81
 FWD_GFLOP_PER_IMAGE_F64 = 1.0695
 # timer groups that are launches of ONE kernel symbol (rocprofv3 --stats adds them up under that name)
-SYMBOL_OF = {"chain_fwd@15x15": "k_block_chain_x3@15x15", "chain_bwd@15x15": "k_block_chain_x3@15x15"}
+SYMBOL_OF = {   # timer group -> kernel symbol (template instantiation) it launches on the default path; groups that share a symbol merge
+    "chain_fwd@15x15": "k_block_chain_ps<false>@15x15", "chain_bwd@15x15": "k_block_chain_ps<true>@15x15",
+    "conv3x3_wgrad@60x60": "k_wgrad3x3_ps<64,true>@60x60", "conv3x3_wgrad@30x30": "k_wgrad3x3_ps<32,true>@30x30",
+    "conv3x3_wgrad@15x15": "k_wgrad3x3_ps<16,true>@15x15",
+    "conv3x3_fwd@60x60": "k_conv3x3_ps<FWD_FULL,64>@60x60", "conv3x3_fwd@30x30": "k_conv3x3_ps<FWD_FULL,32>@30x30",
+    "conv3x3_fwd_pool@60x60": "k_conv3x3_ps<FWD_POOL,64>@60x60", "conv3x3_fwd_pool@30x30": "k_conv3x3_ps<FWD_POOL,32>@30x30",
+    "conv3x3_dgrad@60x60": "k_conv3x3_ps<DGRAD_ACT,64>@60x60", "conv3x3_dgrad@30x30": "k_conv3x3_ps<DGRAD_ACT,32>@30x30",
+    "conv3x3_dgrad_unpool@60x60": "k_conv3x3_ps<DGRAD_ADDPOOL,64>@60x60", "conv3x3_dgrad_unpool@30x30": "k_conv3x3_ps<DGRAD_ADDPOOL,32>@30x30",
+}
 
 
 def self_launch(args) -> int:
@@ -425,9 +433,10 @@ def main():
             table[k] = {"ms_per_step": round(tot / n_timed, 4), "avg_launch_ms": round(avg, 4), "bound": bound,
                         "t_roof_ms": round(troof, 4), "frac": round(troof / avg, 4) if troof > 0 else None}
         # dominant kernel SYMBOL: groups that launch the same kernel are added up (what rocprofv3 --stats shows)
+        symmap = SYMBOL_OF if getattr(model.engine, "ps", False) else {"chain_fwd@15x15": "k_block_chain_x3<false>@15x15", "chain_bwd@15x15": "k_block_chain_x3<false>@15x15"}
         sym = {}
         for k, (n_l, tot, fl, nb) in per.items():
-            e = sym.setdefault(SYMBOL_OF.get(k, k), [0, 0.0, 0.0, 0.0, []])
+            e = sym.setdefault(symmap.get(k, k), [0, 0.0, 0.0, 0.0, []])
             e[0] += n_l; e[1] += tot; e[2] += fl * n_l; e[3] += nb * n_l; e[4].append(k)
         dom = max(sym, key=lambda k: sym[k][1])
         n_l, tot_ms, fl_tot, nb_tot, dom_groups = sym[dom]

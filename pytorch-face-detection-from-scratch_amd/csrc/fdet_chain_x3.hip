@@ -89,6 +89,9 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], bool b0, bool b1)
 }
 
 typedef __attribute__((address_space(3))) void* lds_void_t;
+#ifndef CH_DBG
+#define CH_DBG 0            // timing ablations (wrong results): 1 no epilogue, 2 no deferred jobs, 4 no MFMAs
+#endif
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // (an element of an ext-vector is copied to a scalar before any bit cast: see fdet_wgrad3x3_ps.hip)
 __device__ __forceinline__ unsigned ch_elem(const u32x2& v, int k) { return k ? v.y : v.x; }
@@ -496,13 +499,264 @@ k_block_chain_x3(const ChainArgs a) {
   }
 }
 
+// ---- PS flavour, epilogue pipelined across the layer boundary --------------------------------------------------
+// Layer L+1's chunk c only reads the 16-channel group c of layer L's output, and there is a workgroup barrier at the end
+// of every chunk anyway.  So layer L's epilogue does its arithmetic, writes group 0 (X in LDS + the PS tensor in HBM) and
+// passes the barrier; groups 1, 2, 3 wait in 48 registers and are split / written as four "jobs" per chunk (taps 1, 3,
+// 5, 7) of layer L+1's chunks 0, 1, 2, behind its MFMAs.  Everything a job does is branch-free so that it can sit in one
+// scheduling region with the MFMAs: lanes of pad positions write LDS to a per-lane dummy slot and HBM through a buffer
+// descriptor at an out-of-range offset (dropped); a tensor that is not kept has an EMPTY descriptor.  Store counts are
+// therefore exact -- 12 per piece -- and the waits for the weight ring are counted (vmcnt 12 / 24), not drains.
+template <bool BWD>
+__global__ void __launch_bounds__(NTHR, 1)
+k_block_chain_ps(const ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x8* X = reinterpret_cast<bf16x8*>(smem);                 // [c16 4][hl 2][kh 2][PT] units
+  const int PT = a.PT, WP = a.WP;
+  bf16x8* Wb = X + 16 * PT;                                     // 2 buffers x [hi A_UNITS | lo A_UNITS]
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int n = blockIdx.x;
+  const int HW = a.H * a.W;
+  const bool qb0 = l31 & 1, qb1 = l31 & 2;
+  const unsigned dmy = (unsigned)(16 * PT + 4 * A_UNITS) * 16u + (unsigned)tid * 8u;   // this lane's dummy LDS slot
+  float* const Lb = reinterpret_cast<float*>(smem + (size_t)(16 * PT + 4 * A_UNITS) * 16 + NTHR * 8);   // [layer][64] biases (fwd)
+  float* const Ls = Lb + MAXL * FCH;                           // [layer / 2][64] dropout scales of this image (odd layers)
+  bool valid[NT];
+  int xslot[NT], nv4[NT], ebase4[NT];
+  unsigned psb[NT], xw[NT], pso[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int q = wid * (32 * NT) + j * 32 + l31;
+    const int pr = q / WP, pc = q - pr * WP;
+    valid[j] = pr < a.H && pc < a.W;
+    xslot[j] = q + WP + 1;
+    const int q4 = q & ~3, pr4 = q4 / WP, pc4 = q4 - pr4 * WP;
+    nv4[j] = pr4 < a.H ? max(0, min(4, a.W - pc4)) : 0;
+    ebase4[j] = (n * FCH + 4 * half + (l31 & 3)) * HW + (nv4[j] > 0 ? pr4 * a.W + pc4 : 0);
+    psb[j] = (unsigned)(n * a.ps_img + (valid[j] ? pr * a.ps_wp + pc + 1 : 0)) * 16u + 8u * half;
+    xw[j] = (unsigned)xslot[j] * 16u + 8u * half;
+    pso[j] = valid[j] ? psb[j] : 0x80000000u;
+  }
+  const unsigned ps_g = (unsigned)a.ps_hpwp * 16u, ps_lo = (unsigned)a.ps_plane * 16u;
+  const int ps_bytes = (int)((unsigned)a.N * (unsigned)a.ps_img * 16u);
+
+  const unsigned lds_w = (unsigned)(size_t)(lds_void_t)smem + (unsigned)(16 * PT) * 16u;
+  const unsigned wvoff = (unsigned)lane * 16u;
+  const unsigned wpiece = (unsigned)((wid >> 1) * A_UNITS + (wid & 1) * 576) * 16u;
+  const unsigned wsrc = (unsigned)((wid >> 1) * 4 * A_UNITS + (wid & 1) * 576) * 16u;
+  CH_DMA_W(0, 0, 0)
+  {
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    for (int t = tid; t < 16 * PT; t += NTHR) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = tid; t < a.nlayers * FCH; t += NTHR) {
+      const int l_ = t >> 6, ch_ = t & 63;
+      if (!BWD) Lb[t] = a.bias[l_][ch_];
+      if (l_ & 1) Ls[(l_ >> 1) * FCH + ch_] = a.sc[l_] ? a.sc[l_][n * FCH + ch_] : 1.f;
+    }
+  }
+  // a per-channel vector of the LDS tables in tile layout
+#define CHP_LDS_TILE(DST, TAB)                                                                     \
+  {                                                                                                \
+    _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                               \
+      _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                           \
+        const f32x4 v_ = *reinterpret_cast<const f32x4*>((TAB) + 32 * m_ + 8 * g_ + 4 * half);    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) DST[m_][4 * g_ + i_] = v_[i_];            \
+      }                                                                                            \
+  }
+
+  // one job: four values (position tile J, 16-channel group P, k half HH) -> hi / lo split -> X, PS tensor, c's hi plane
+#define CHP_SUB(F0, F1, F2, F3, J, P, HH)                                                     \
+  {                                                                                                \
+    const float f_[4] = {F0, F1, F2, F3};                                                          \
+    unsigned hi_[2], lo_[2];                                                                       \
+    ps_split4(f_, hi_, lo_);                                                                       \
+    const unsigned ah_ = (unsigned)((((P) * 2 + 0) * 2 + (HH)) * PT) * 16u, al_ = (unsigned)((((P) * 2 + 1) * 2 + (HH)) * PT) * 16u; \
+    *reinterpret_cast<u32x2*>(smem + (valid[J] ? ah_ + xw[J] : dmy)) = u32x2{hi_[0], hi_[1]};      \
+    *reinterpret_cast<u32x2*>(smem + (valid[J] ? al_ + xw[J] : dmy)) = u32x2{lo_[0], lo_[1]};      \
+    const unsigned go_ = pso[J] + (unsigned)(4 * ((P) >> 1) + 2 * ((P) & 1) + (HH)) * ps_g;        \
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{hi_[0], hi_[1]}, tgt_rs, go_, 0, 0);               \
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo_[0], lo_[1]}, tgt_rs, go_, ps_lo, 0);           \
+  }
+  // group 0 of a finished tile now; groups 1..3 into the pending registers
+#define CHP_HAND_OVER(V)                                                                           \
+  {                                                                                                \
+    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                              \
+      _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                             \
+        CHP_SUB(V[j_][0][4 * h_], V[j_][0][4 * h_ + 1], V[j_][0][4 * h_ + 2], V[j_][0][4 * h_ + 3], j_, 0, h_) \
+    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                              \
+      _Pragma("unroll") for (int p_ = 1; p_ < 4; ++p_)                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) pend[j_][p_ - 1][i_] = V[j_][p_ >> 1][8 * (p_ & 1) + i_]; \
+  }
+  __amdgpu_buffer_rsrc_t tgt_rs = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000);
+#define CHP_TARGET(PTR) __builtin_amdgcn_make_buffer_rsrc((void*)(PTR), 0, (PTR) ? ps_bytes : 0, 0x00020000)
+  float pend[NT][3][8];
+  int young = 0;                                                // stores issued after the DMA of the next layer's chunk 1
+
+  f32x16 Hreg[NT][2];                                           // skip connection / running gradient
+  u32x2 auxb[NT][2][4];                                         // raw PS hi pieces of the lrelu' operand (bwd)
+  if (a.psio & 2) CH_LOAD_PS(Hreg, a.in) else CH_LOAD_TILE(Hreg, a.in)
+  if (BWD) CH_LOAD_HI(auxb, a.pre_ld)
+  __syncthreads();                                              // zero fill done
+  if (!BWD) {
+    CHP_HAND_OVER(Hreg)
+  } else {                                                      // dz2 of the first block to run = dout * scale * lrelu'(c)
+    f32x16 t[NT][2], s2[2];
+    CH_SCALE_TILE(s2, a.pre_sc)
+    CH_FOR_ALL t[j][m][r] = Hreg[j][m][r] * s2[m][r] * (CH_POS(auxb, j, m, r) ? 1.f : a.slope);
+    tgt_rs = CHP_TARGET(a.pre_st);
+    CHP_HAND_OVER(t)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // first weight chunk landed
+  __syncthreads();
+  CH_DMA_W(0, 1, 1)
+
+  int tapoff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tapoff[t] = (t / 3) * WP + (t % 3);
+  const int w_off = half * FCH + l31;
+  const int x_off = half * PT + wid * (32 * NT) + l31;
+
+  for (int L = 0; L < a.nlayers; ++L) {
+    f32x16 acc[NT][2];
+    const bool odd = L & 1, last = L + 1 == a.nlayers;
+    if (!BWD) {                                                 // the sums start from the bias
+      f32x16 b0[2];
+      CHP_LDS_TILE(b0, Lb + L * FCH)
+      CH_FOR_ALL acc[j][m][r] = b0[m][r];
+    } else {
+      CH_FOR_ALL acc[j][m][r] = 0.f;
+    }
+    if (BWD && a.ld[L]) CH_LOAD_HI(auxb, a.ld[L])               // the lrelu' operand of this layer's epilogue
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // weight ring (buffer c & 1 holds chunk c): chunk 1 of a layer was issued before the previous epilogue
+      if (c == 1 || c == 2) CH_DMA_W(L, c + 1, (c & 1) ^ 1)
+      else if (c == 3 && !last) CH_DMA_W(L + 1, 0, 0)
+      const bf16x8* Ww = Wb + (c & 1) * 2 * A_UNITS + w_off;
+      const bf16x8* Xh = X + (c * 2 + 0) * 2 * PT + x_off;
+      const bf16x8* Xl = X + (c * 2 + 1) * 2 * PT + x_off;
+      bf16x8 wh[2][2], wl[2][2], xh[2][NT], xl[2][NT];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) { wh[0][m] = Ww[m * 32]; wl[0][m] = Ww[A_UNITS + m * 32]; }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) { xh[0][j] = Xh[tapoff[0] + j * 32]; xl[0][j] = Xl[tapoff[0] + j * 32]; }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        if (t + 1 < 9) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            wh[nxt][m] = Ww[(t + 1) * 2 * FCH + m * 32];
+            wl[nxt][m] = Ww[A_UNITS + (t + 1) * 2 * FCH + m * 32];
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            xh[nxt][j] = Xh[tapoff[t + 1] + j * 32];
+            xl[nxt][j] = Xl[tapoff[t + 1] + j * 32];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);                      // keep the fragment reads one tap ahead of their MFMAs
+        if (CH_DBG & 4) { acc[0][0][0] += (float)wh[cur][0][0] + (float)wl[cur][1][0] + (float)xh[cur][0][0] + (float)xl[cur][1][0] + (float)wh[cur][1][0] + (float)wl[cur][0][0] + (float)xh[cur][1][0] + (float)xl[cur][0][0]; } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cur][m], xl[cur][j], acc[j][m], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cur][m], xh[cur][j], acc[j][m], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cur][m], xh[cur][j], acc[j][m], 0, 0, 0);
+        }
+        if (!(CH_DBG & 2) && c < 3 && (t & 1)) {                // a pending job of the previous layer's group c + 1
+          constexpr int dummy_ = 0; (void)dummy_;
+          const int jj = (t - 1) >> 2, hh = ((t - 1) >> 1) & 1;
+          CHP_SUB(pend[jj][c][4 * hh], pend[jj][c][4 * hh + 1], pend[jj][c][4 * hh + 2], pend[jj][c][4 * hh + 3], jj, c + 1, hh)
+#pragma unroll
+          for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            if (i == 8 || i == 9) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (i >= 10) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // this wave's pieces of the next chunk have landed: everything issued after them is the 8 job stores of this chunk
+      // (chunks 0..2) and, after chunk 0, the `young` stores of the previous epilogue (8 of group 0, 16 more for c's hi plane)
+      if (c == 0) { if (young == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (young == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
+      else if (c < 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                          // chunk consumed by every wave; next one visible
+    }
+    if (!last) CH_DMA_W(L + 1, 1, 1)                            // buffer of chunk 3 is free: next layer's chunk 1
+
+    // ---- epilogue arithmetic for the whole tile (in place), then group 0 now and groups 1..3 handed to the next layer
+    young = 8;
+    if (CH_DBG & 1) {
+    } else if (!BWD) {
+      CH_FOR_ALL { const float t = acc[j][m][r]; acc[j][m][r] = t > 0.f ? t : t * a.slope; }
+      if (!odd) {
+        tgt_rs = CHP_TARGET(a.st[L]);
+        CHP_HAND_OVER(acc)
+      } else {
+        // c: only its hi plane (its signs) is kept -- stored here for the whole tile, 16 exact-count stores
+        const __amdgpu_buffer_rsrc_t crs = CHP_TARGET(a.st[L]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+              const bf16x2_t h0 = {(__bf16)acc[j][m][4 * g], (__bf16)acc[j][m][4 * g + 1]}, h1 = {(__bf16)acc[j][m][4 * g + 2], (__bf16)acc[j][m][4 * g + 3]};
+              __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)}, crs,
+                                                    pso[j] + (unsigned)(4 * m + g) * ps_g, 0, 0);
+            }
+        f32x16 s2[2];
+        CHP_LDS_TILE(s2, Ls + (L >> 1) * FCH)
+        CH_FOR_ALL Hreg[j][m][r] = acc[j][m][r] * s2[m][r] + Hreg[j][m][r];
+        if (last) {
+          CH_STORE_TILE(a.st2[L], Hreg)                         // chain output, fp32 NCHW
+        } else {
+          tgt_rs = CHP_TARGET(a.st2[L]);
+          CHP_HAND_OVER(Hreg)
+          young = 24;
+        }
+      }
+    } else {
+      if (!odd) {                                               // conv2^T: dz1 = acc * lrelu'(a)
+        CH_FOR_ALL acc[j][m][r] *= (CH_POS(auxb, j, m, r) ? 1.f : a.slope);
+        tgt_rs = CHP_TARGET(a.st[L]);
+        CHP_HAND_OVER(acc)
+      } else {                                                  // conv1^T: dx = acc + dout
+        CH_FOR_ALL Hreg[j][m][r] += acc[j][m][r];
+        if (last) {
+          CH_STORE_TILE(a.st2[L], Hreg)                         // gradient w.r.t. the chain input, fp32 NCHW
+        } else {                                                // dz2 of the next block to run
+          f32x16 s2[2];
+          CHP_LDS_TILE(s2, Ls + (L >> 1) * FCH)
+          CH_FOR_ALL acc[j][m][r] = Hreg[j][m][r] * s2[m][r] * (CH_POS(auxb, j, m, r) ? 1.f : a.slope);
+          tgt_rs = CHP_TARGET(a.st2[L]);
+          CHP_HAND_OVER(acc)
+        }
+      }
+    }
+    __syncthreads();                                            // group 0 of the new X visible
+  }
+}
+
+
 int chain_geometry(int F, int H, int W, int& WP, int& PT, size_t& lds) {
   if (F != FCH || H <= 0 || W <= 0) return 0;
   WP = (W + 1 + 3) / 4 * 4;
   if (H * WP > 4 * NT * 32) return 0;                           // 4 waves x 64 positions
   PT = (H + 2) * WP + 3;
   if (PT < 4 * NT * 32 + 2 * WP + 3) PT = 4 * NT * 32 + 2 * WP + 3;   // garbage positions of the last wave read in range
-  lds = ((size_t)16 * PT + 2 * 2 * A_UNITS) * 16;
+  lds = ((size_t)16 * PT + 2 * 2 * A_UNITS) * 16 + (size_t)NTHR * 8 + (size_t)(MAXL + MAXL / 2) * FCH * 4;   // + one 8-byte dummy slot per lane, bias and scale tables (PS flavour)
   return lds <= 160 * 1024;
 }
 
@@ -512,9 +766,12 @@ int launch_chain(ChainArgs& a, hipStream_t st) {
     return fail(FDET_EINVAL, "block_chain_bf16x3: unsupported map %dx%d (needs 64 channels and H*roundup4(W+1) <= 256)", a.H, a.W);
   if ((size_t)a.N * FCH * a.H * a.W >= ((size_t)1 << 31)) return fail(FDET_EINVAL, "block_chain_bf16x3: tensor too large");
   { const char* e_ = FDET_ENV_ONCE("FDET_CHAIN_STAGGER"); a.stagger = e_ ? atoi(e_) : 0; }
-  if (a.psio & 1) {
-    { if (int rc_ = set_lds_attr((const void*)k_block_chain_x3<true>, (size_t)(lds), __func__)) return rc_; }
-    hipLaunchKernelGGL(k_block_chain_x3<true>, dim3(a.N), dim3(NTHR), lds, st, a);
+  if ((a.psio & 1) && a.bwd) {
+    { if (int rc_ = set_lds_attr((const void*)k_block_chain_ps<true>, (size_t)(lds), __func__)) return rc_; }
+    hipLaunchKernelGGL(k_block_chain_ps<true>, dim3(a.N), dim3(NTHR), lds, st, a);
+  } else if (a.psio & 1) {
+    { if (int rc_ = set_lds_attr((const void*)k_block_chain_ps<false>, (size_t)(lds), __func__)) return rc_; }
+    hipLaunchKernelGGL(k_block_chain_ps<false>, dim3(a.N), dim3(NTHR), lds, st, a);
   } else {
     { if (int rc_ = set_lds_attr((const void*)k_block_chain_x3<false>, (size_t)(lds), __func__)) return rc_; }
     hipLaunchKernelGGL(k_block_chain_x3<false>, dim3(a.N), dim3(NTHR), lds, st, a);
@@ -591,7 +848,7 @@ extern "C" int fdet_block_chain_bwd_bf16x3(const float* dout, const void* const*
 namespace {
 int chain_ps_geo(ChainArgs& a, int N, int H, int W) {
   PsGeo g;
-  if (!ps_geo(N, FCH, H, W, g) || (unsigned long long)(N + 1) * g.img * 16ull >= (1ull << 32)) return 0;
+  if (!ps_geo(N, FCH, H, W, g) || (unsigned long long)(N + 1) * g.img * 16ull >= (1ull << 31)) return 0;
   a.ps_hpwp = g.HP * g.WP; a.ps_wp = g.WP; a.ps_plane = g.plane; a.ps_img = g.img;
   return 1;
 }
