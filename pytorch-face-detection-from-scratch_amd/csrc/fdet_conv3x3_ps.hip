@@ -82,7 +82,7 @@ __device__ __forceinline__ void ps_acc_read(const f32x16& acc, const int r, floa
 // of the main loop rely on.
 template <int MODE>
 __device__ __forceinline__ void ps_unit(const f32x16& acc, const int gp, const float (&bza)[4], const float (&bzb)[4],
-                                        const u32x2_t (&sg)[4], const float slope, const bool ok, const int ob, const int m,
+                                        const u32x2_t (&sg)[2], const float slope, const bool ok, const int ob, const int m,
                                         const int half, const int gstride, const int plane_o_bytes,
                                         const __amdgpu_buffer_rsrc_t yrs) {
   float za[4], zb[4];
@@ -107,8 +107,9 @@ __device__ __forceinline__ void ps_unit(const f32x16& acc, const int gp, const f
   } else if (MODE == PSE_DGRAD_ACT) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      za[i] *= ps_join(sg[0][i >> 1], sg[1][i >> 1], i & 1) > 0.f ? 1.f : slope;
-      zb[i] *= ps_join(sg[2][i >> 1], sg[3][i >> 1], i & 1) > 0.f ? 1.f : slope;
+      // the hi part carries the sign of the saved activation (it is zero only for a zero): its lo plane is not read
+      za[i] *= ps_join(sg[0][i >> 1], 0u, i & 1) > 0.f ? 1.f : slope;
+      zb[i] *= ps_join(sg[1][i >> 1], 0u, i & 1) > 0.f ? 1.f : slope;
     }
   }
   unsigned ha[2], la[2], hb[2], lb[2];
@@ -133,7 +134,7 @@ __device__ __forceinline__ void ps_unit(const f32x16& acc, const int gp, const f
 template <int MODE, int WP>
 __global__ void __launch_bounds__(256, 1)
 k_conv3x3_ps(const PsConvArgs p) {
-  constexpr bool WOVEN = MODE == PSE_FWD_FULL;
+  constexpr bool WOVEN = MODE == PSE_FWD_FULL || MODE == PSE_DGRAD_ACT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16x8* const lds = reinterpret_cast<bf16x8*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -238,7 +239,27 @@ k_conv3x3_ps(const PsConvArgs p) {
       ob[n_] = nn_ * p.img_o + y_ * WP + col_ + 1;                                                 \
     }                                                                                              \
   }
-  const u32x2_t sg0[4] = {};                             // placeholder of the sign operand in the forward mode
+  // DGRAD_ACT, woven: hi pieces of the saved activation at the PREVIOUS tile's positions (groups 4m+2gp, 4m+2gp+1),
+  // loaded when that tile's geometry is known and consumed by its units behind the next tile's first two chunks
+  u32x2_t sgp[4][2][2][2];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) sgp[n][m][gp][0] = sgp[n][m][gp][1] = u32x2_t{0u, 0u};
+#define PS_SIGNS()                                                                                 \
+  {                                                                                                \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                \
+      const u32x2_t* ap = reinterpret_cast<const u32x2_t*>(p.aux + (okn[n] ? ob[n] : 0)) + half;   \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
+        _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                         \
+          const size_t ga = (size_t)(4 * m + 2 * gp) * gstride, gb = ga + (size_t)gstride;         \
+          sgp[n][m][gp][0] = ap[ga * 2];                                                           \
+          sgp[n][m][gp][1] = ap[gb * 2];                                                           \
+        }                                                                                          \
+    }                                                                                              \
+  }
 
   int young = 0;                                         // stores of this wave younger than its last DMA: 0, 16 or 32
   int sb = 0;
@@ -247,7 +268,7 @@ k_conv3x3_ps(const PsConvArgs p) {
 #define PS_OPEN()                                                                                  \
   {                                                                                                \
     if (young == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               \
-    PS_WAITN(8) PS_WAITN(12) PS_WAITN(16) PS_WAITN(32) PS_WAITN(36) PS_WAITN(40) PS_WAITN(44) PS_WAITN(63) \
+    PS_WAITN(8) PS_WAITN(12) PS_WAITN(16) PS_WAITN(32) PS_WAITN(36) PS_WAITN(40) PS_WAITN(44) PS_WAITN(48) PS_WAITN(63) \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
     __builtin_amdgcn_s_barrier();                                                                  \
   }
@@ -297,7 +318,7 @@ k_conv3x3_ps(const PsConvArgs p) {
       }                                                                                            \
       if ((JOB) != 0 && t < 8 && !(PS_DBG & 1)) {                                                  \
         const int n_ = ((JOB) - 1) * 2 + (t >> 2), m_ = (t >> 1) & 1, gp_ = t & 1;                 \
-        ps_unit<MODE>(PREV[WOVEN ? m_ : 0][WOVEN ? n_ : 0], gp_, bz[m_][2 * gp_], bz[m_][2 * gp_ + 1], sg0, p.slope, okn[n_], ob[n_], m_, \
+        ps_unit<MODE>(PREV[WOVEN ? m_ : 0][WOVEN ? n_ : 0], gp_, bz[m_][2 * gp_], bz[m_][2 * gp_ + 1], sgp[n_][m_][gp_], p.slope, okn[n_], ob[n_], m_, \
                       half, gstride, plane_o_bytes, yrs);                                          \
       }                                                                                            \
       /* the next tap's twelve fragment reads ride one per MFMA on the first half of this tap, the unit's VALU  */ \
@@ -444,25 +465,11 @@ k_conv3x3_ps(const PsConvArgs p) {
   if constexpr (MODE == PSE_FWD_POOL) { PS_EPI_FWD_POOL(ACC, tile) }                               \
   else if constexpr (MODE == PSE_DGRAD_ADDPOOL) { PS_EPI_ADDPOOL(ACC, tile) }                      \
   else if (!(PS_DBG & 1)) {                                                                        \
-    u32x2_t sg[MODE == PSE_DGRAD_ACT ? 4 : 1][2][2][4];                                            \
-    if (MODE == PSE_DGRAD_ACT) {                                                                   \
-      /* the saved activation: this lane's 4 channels (8 bytes) of groups 4m+2gp and 4m+2gp+1, hi and lo */ \
-      _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                              \
-        const u32x2_t* ap = reinterpret_cast<const u32x2_t*>(p.aux + (okn[n] ? ob[n] : 0)) + half; \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                              \
-          _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                       \
-            const size_t ga = (size_t)(4 * m + 2 * gp) * gstride, gb = ga + (size_t)gstride;       \
-            sg[n][m][gp][0] = ap[ga * 2];                                                          \
-            sg[n][m][gp][1] = ap[(ga + p.plane_o) * 2];                                            \
-            sg[n][m][gp][2] = ap[gb * 2];                                                          \
-            sg[n][m][gp][3] = ap[(gb + p.plane_o) * 2];                                            \
-          }                                                                                        \
-      }                                                                                            \
-    }                                                                                              \
+    if (MODE == PSE_DGRAD_ACT) PS_SIGNS()                                                          \
     _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                  \
       _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
         _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                           \
-          ps_unit<MODE>(ACC[m][n], gp, bz[m][2 * gp], bz[m][2 * gp + 1], sg[MODE == PSE_DGRAD_ACT ? n : 0][m][gp], p.slope, \
+          ps_unit<MODE>(ACC[m][n], gp, bz[m][2 * gp], bz[m][2 * gp + 1], sgp[n][m][gp], p.slope,  \
                         okn[n], ob[n], m, half, gstride, plane_o_bytes, yrs);                      \
   } else {                                                                                         \
     _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
@@ -485,6 +492,10 @@ k_conv3x3_ps(const PsConvArgs p) {
       young = 0;                                                                                   \
     }                                                                                              \
     PS_GEO(tile)                                                                                   \
+    if (WOVEN && MODE == PSE_DGRAD_ACT && !(PS_DBG & 1)) {                                         \
+      PS_SIGNS()                                                                                   \
+      young += 32;                                                                                 \
+    }                                                                                              \
     if (!WOVEN) {                                                                                  \
       PS_EPILOGUE(ACC)                                                                             \
       young = (PS_DBG & 1) ? 0 : (POOLM ? pool_cnt : 32);                                          \
@@ -516,6 +527,7 @@ k_conv3x3_ps(const PsConvArgs p) {
 #undef PS_NEXT
 #undef PS_OPEN
 #undef PS_GEO
+#undef PS_SIGNS
 #undef PS_DMA
 #undef PS_ROWOFF
 }
