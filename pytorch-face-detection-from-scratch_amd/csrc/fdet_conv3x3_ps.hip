@@ -134,7 +134,7 @@ __device__ __forceinline__ void ps_unit(const f32x16& acc, const int gp, const f
 template <int MODE, int WP>
 __global__ void __launch_bounds__(256, 1)
 k_conv3x3_ps(const PsConvArgs p) {
-  constexpr bool WOVEN = MODE == PSE_FWD_FULL || MODE == PSE_DGRAD_ACT;
+  constexpr bool WOVEN = MODE == PSE_FWD_FULL || MODE == PSE_DGRAD_ACT || MODE == PSE_DGRAD_ADDPOOL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16x8* const lds = reinterpret_cast<bf16x8*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -317,9 +317,29 @@ k_conv3x3_ps(const PsConvArgs p) {
           }                                                                                        \
       }                                                                                            \
       if ((JOB) != 0 && t < 8 && !(PS_DBG & 1)) {                                                  \
-        const int n_ = ((JOB) - 1) * 2 + (t >> 2), m_ = (t >> 1) & 1, gp_ = t & 1;                 \
-        ps_unit<MODE>(PREV[WOVEN ? m_ : 0][WOVEN ? n_ : 0], gp_, bz[m_][2 * gp_], bz[m_][2 * gp_ + 1], sgp[n_][m_][gp_], p.slope, okn[n_], ob[n_], m_, \
-                      half, gstride, plane_o_bytes, yrs);                                          \
+        if constexpr (MODE == PSE_DGRAD_ADDPOOL) {                                                 \
+          /* two (channel, window) items of the previous tile: dx rows y, y+1 = acc + routed pooled gradient */ \
+          _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {                                       \
+            const int it_ = ((JOB) - 1) * 16 + 2 * t + e_;                                         \
+            const int m_ = it_ >> 4, gp_ = (it_ >> 3) & 1, ab_ = (it_ >> 2) & 1, i_ = it_ & 3;     \
+            const int arg_ = (int)((rkp[m_][gp_][ab_] >> (8 * i_ + 4)) & 3u);                      \
+            const float gv_ = dgp[m_][gp_][ab_][i_];                                               \
+            const int so_ = (32 * m_ + 16 * gp_ + 8 * ab_ + i_) * p.H * p.W * 4;                   \
+            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                     \
+              float z0_, z1_;                                                                      \
+              ps_acc_read(PREV[WOVEN ? m_ : 0][WOVEN ? 2 * r_ : 0], 8 * gp_ + 4 * ab_ + i_, z0_);  \
+              ps_acc_read(PREV[WOVEN ? m_ : 0][WOVEN ? 2 * r_ + 1 : 0], 8 * gp_ + 4 * ab_ + i_, z1_); \
+              z0_ += arg_ == 2 * r_ ? gv_ : 0.f;                                                   \
+              z1_ += arg_ == 2 * r_ + 1 ? gv_ : 0.f;                                               \
+              __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(unsigned, z0_), __builtin_bit_cast(unsigned, z1_)}, prs, sto, \
+                                                    so_ + r_ * p.W * 4, 0);                        \
+            }                                                                                      \
+          }                                                                                        \
+        } else {                                                                                   \
+          const int n_ = ((JOB) - 1) * 2 + (t >> 2), m_ = (t >> 1) & 1, gp_ = t & 1;               \
+          ps_unit<MODE>(PREV[WOVEN ? m_ : 0][WOVEN ? n_ : 0], gp_, bz[m_][2 * gp_], bz[m_][2 * gp_ + 1], sgp[n_][m_][gp_], p.slope, okn[n_], ob[n_], m_, \
+                        half, gstride, plane_o_bytes, yrs);                                        \
+        }                                                                                          \
       }                                                                                            \
       /* the next tap's twelve fragment reads ride one per MFMA on the first half of this tap, the unit's VALU  */ \
       /* work three per gap, its two stores near the end                                                        */ \
@@ -331,7 +351,7 @@ k_conv3x3_ps(const PsConvArgs p) {
       _Pragma("unroll") for (int i = 0; i < 12; ++i) {                                             \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
         if ((JOB) != 0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                         \
-        if ((JOB) != 0 && i >= 10) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);              \
+        if ((JOB) != 0 && (i >= 10 || (MODE == PSE_DGRAD_ADDPOOL && i >= 8))) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0); \
       }                                                                                            \
     }                                                                                              \
     sb ^= 1;                                                                                       \
@@ -348,6 +368,39 @@ k_conv3x3_ps(const PsConvArgs p) {
     const int nn = (int)__umulhi((unsigned)v_, p.magic_hp), y = v_ - nn * HP;                      \
     const int xp = WP == 64 ? l31 : (l31 & 15), yp = y >> 1;                                       \
     const bool okw = nn < p.N && y < p.H && 2 * xp < p.W;
+  // DGRAD_ADDPOOL, woven: the pooled gradient and routing bytes of the PREVIOUS tile's windows (40 loads, always issued:
+  // a lane without a window reads element 0) and the byte offset of its first dx element (out of range without a window)
+  float dgp[2][2][2][4];
+  unsigned rkp[2][2][2];
+  unsigned sto = 0x80000000u;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab) {
+        rkp[m][gp][ab] = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dgp[m][gp][ab][i] = 0.f;
+      }
+#define PS_POOLPREF(T)                                                                             \
+  {                                                                                                \
+    PS_WIN(T)                                                                                      \
+    const int HWp = p.Hp * p.Wp;                                                                   \
+    const int pbase = okw ? (nn * 64 * p.Hp + yp) * p.Wp + xp : 0;                                 \
+    const int rbase = okw ? (nn * 8 * p.Hp + yp) * p.Wp + xp : 0;                                  \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                             \
+        _Pragma("unroll") for (int ab = 0; ab < 2; ++ab) {                                         \
+          const int G = 4 * m + 2 * gp + ab;                                                       \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+            const float v_ = p.dout[pbase + (8 * G + 4 * half + i) * HWp];                         \
+            dgp[m][gp][ab][i] = okw ? v_ : 0.f;                                                    \
+          }                                                                                        \
+          rkp[m][gp][ab] = *reinterpret_cast<const unsigned*>(p.route_in + (size_t)(rbase + G * HWp) * 8 + 4 * half); \
+        }                                                                                          \
+    sto = okw ? (unsigned)(((nn * 64 + 4 * half) * p.H + y) * p.W + 2 * xp) * 4u : 0x80000000u;    \
+  }
   // maxpool2x2(lrelu(acc + bias) * scale + skip) -> pooled PS / fp32 NCHW, routing bytes.  Every load first; stores are
   // buffer stores with the validity in the offset (exactly pool_cnt per wave, counted by the next tile's first wait).
 #define PS_EPI_FWD_POOL(ACC, T)                                                                    \
@@ -462,8 +515,8 @@ k_conv3x3_ps(const PsConvArgs p) {
   }
   // the whole epilogue of ACC (geometry in ob / okn) at once: every load precedes the first store
 #define PS_EPILOGUE(ACC)                                                                           \
-  if constexpr (MODE == PSE_FWD_POOL) { PS_EPI_FWD_POOL(ACC, tile) }                               \
-  else if constexpr (MODE == PSE_DGRAD_ADDPOOL) { PS_EPI_ADDPOOL(ACC, tile) }                      \
+  if constexpr (MODE == PSE_FWD_POOL) { PS_EPI_FWD_POOL(ACC, etile) }                              \
+  else if constexpr (MODE == PSE_DGRAD_ADDPOOL) { PS_EPI_ADDPOOL(ACC, etile) }                     \
   else if (!(PS_DBG & 1)) {                                                                        \
     if (MODE == PSE_DGRAD_ACT) PS_SIGNS()                                                          \
     _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                  \
@@ -481,7 +534,7 @@ k_conv3x3_ps(const PsConvArgs p) {
     PS_OPEN()                                                                                      \
     PS_NEXT(0)                                                                                     \
     PS_BODY(ACC, 1, (WOVEN ? 1 : 0), PREV)                                                         \
-    young = (WOVEN && !(PS_DBG & 1)) ? 16 : 0;                                                     \
+    young = (WOVEN && !(PS_DBG & 1)) ? (MODE == PSE_DGRAD_ADDPOOL ? 32 : 16) : 0;                  \
     PS_OPEN()                                                                                      \
     PS_NEXT(1)                                                                                     \
     PS_BODY(ACC, 0, (WOVEN ? 2 : 0), PREV)                                                         \
@@ -492,9 +545,16 @@ k_conv3x3_ps(const PsConvArgs p) {
       young = 0;                                                                                   \
     }                                                                                              \
     PS_GEO(tile)                                                                                   \
+    etile = tile;                                                                                  \
     if (WOVEN && MODE == PSE_DGRAD_ACT && !(PS_DBG & 1)) {                                         \
       PS_SIGNS()                                                                                   \
       young += 32;                                                                                 \
+    }                                                                                              \
+    if constexpr (MODE == PSE_DGRAD_ADDPOOL) {                                                     \
+      if (!(PS_DBG & 1)) {                                                                         \
+        PS_POOLPREF(tile)                                                                          \
+        young = min(young + 40, 63);                                                               \
+      }                                                                                            \
     }                                                                                              \
     if (!WOVEN) {                                                                                  \
       PS_EPILOGUE(ACC)                                                                             \
@@ -502,6 +562,7 @@ k_conv3x3_ps(const PsConvArgs p) {
     }                                                                                              \
   }
 
+  int etile = tile;                                      // the tile whose epilogue PS_EPILOGUE runs (woven: the loop has moved on)
   PS_ROWOFF(tile)
   PS_DMA(0, 0)
   if (WOVEN) {
@@ -520,6 +581,7 @@ k_conv3x3_ps(const PsConvArgs p) {
 #undef PS_EPILOGUE
 #undef PS_EPI_ADDPOOL
 #undef PS_EPI_FWD_POOL
+#undef PS_POOLPREF
 #undef PS_WIN
 #undef PS_WAITN
 #undef PS_BODY
