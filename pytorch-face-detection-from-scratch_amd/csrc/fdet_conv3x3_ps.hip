@@ -603,6 +603,15 @@ int ps_num_cus() {
   return ncu;
 }
 
+// One translation unit per (mode, row width): the woven kernels take a minute or more each to compile, so the Makefile
+// builds this source nine times -- -DPS_TU=<2*mode + (WP == 64)> emits ONE kernel instantiation behind
+// fdet_ps_launch_<n>(), and the plain build keeps the host logic and the C-ABI.
+#ifndef PS_TU
+#define PS_TU (-1)
+#endif
+#define PS_CAT_(a, b) a##b
+#define PS_CAT(a, b) PS_CAT_(a, b)
+#define PS_TU_NAME PS_CAT(fdet_ps_launch_, PS_TU)
 template <int MODE, int WP>
 int launch_ps(const PsConvArgs& p, size_t lds, int grid, hipStream_t st) {
   static bool attr_set = false;
@@ -618,6 +627,19 @@ int launch_ps(const PsConvArgs& p, size_t lds, int grid, hipStream_t st) {
   return check_launch("fdet_conv3x3_ps");
 }
 
+}  // namespace
+#define PS_DECL_LAUNCH(N) extern "C" int fdet_ps_launch_##N(const void* args, size_t lds, int grid, void* stream);
+PS_DECL_LAUNCH(0) PS_DECL_LAUNCH(1) PS_DECL_LAUNCH(2) PS_DECL_LAUNCH(3) PS_DECL_LAUNCH(4) PS_DECL_LAUNCH(5) PS_DECL_LAUNCH(6) PS_DECL_LAUNCH(7)
+#if PS_TU >= 0
+extern "C" int PS_TU_NAME(const void* args, size_t lds, int grid, void* stream) {
+  return launch_ps<PS_TU / 2, (PS_TU & 1) ? 64 : 32>(*reinterpret_cast<const PsConvArgs*>(args), lds, grid, (hipStream_t)stream);
+}
+#endif
+namespace {
+#if PS_TU == -1
+typedef int (*ps_launch_fn)(const void*, size_t, int, void*);
+const ps_launch_fn PS_LAUNCHERS[8] = {fdet_ps_launch_0, fdet_ps_launch_1, fdet_ps_launch_2, fdet_ps_launch_3,
+                                      fdet_ps_launch_4, fdet_ps_launch_5, fdet_ps_launch_6, fdet_ps_launch_7};
 struct PsPoolIO {
   const float* scale = nullptr; void* pool_ps = nullptr; float* pool_f32 = nullptr; unsigned char* route_out = nullptr;
   const float* dout = nullptr; const unsigned char* route_in = nullptr; float* dx_f32 = nullptr;
@@ -665,21 +687,24 @@ int run_ps(int mode, const void* x, const void* wpk, const float* bias, const vo
   switch (mode) {
     case PSE_FWD_FULL:
       FDET_REQUIRE(bias, "conv3x3_ps_fwd: bias is required");
-      return w64 ? launch_ps<PSE_FWD_FULL, 64>(p, lds, grid, st) : launch_ps<PSE_FWD_FULL, 32>(p, lds, grid, st);
+      break;
     case PSE_DGRAD_ACT:
       FDET_REQUIRE(aux, "conv3x3_ps_dgrad_act: the activation is required");
-      return w64 ? launch_ps<PSE_DGRAD_ACT, 64>(p, lds, grid, st) : launch_ps<PSE_DGRAD_ACT, 32>(p, lds, grid, st);
+      break;
     case PSE_FWD_POOL:
       FDET_REQUIRE(bias && aux && (io.pool_ps || io.pool_f32), "conv3x3_ps_fwd_pool: bias, skip and an output are required");
-      return w64 ? launch_ps<PSE_FWD_POOL, 64>(p, lds, grid, st) : launch_ps<PSE_FWD_POOL, 32>(p, lds, grid, st);
+      break;
     default:
       FDET_REQUIRE(io.dout && io.route_in && io.dx_f32, "conv3x3_ps_dgrad_unpool: dout, route and dx are required");
-      return w64 ? launch_ps<PSE_DGRAD_ADDPOOL, 64>(p, lds, grid, st) : launch_ps<PSE_DGRAD_ADDPOOL, 32>(p, lds, grid, st);
+      break;
   }
+  return PS_LAUNCHERS[2 * mode + (w64 ? 1 : 0)](&p, lds, grid, (void*)st);
 }
+#endif  // PS_TU == -1
 
 }  // namespace
 
+#if PS_TU == -1
 // y_ps = LeakyReLU(conv3x3(x_ps, W) + bias); x_ps / y_ps: PS tensors (image 0), wpk: forward panels of
 // fdet_pack_conv3x3_weights_bf16x3
 extern "C" int fdet_conv3x3_ps_fwd(const void* x_ps, const void* wpk, const float* bias, void* y_ps, int N, int Cin,
@@ -714,3 +739,5 @@ extern "C" int fdet_conv3x3_ps_dgrad_unpool(const void* dz_ps, const void* wpk, 
   io.dout = dout_pooled; io.route_in = route8; io.dx_f32 = dx;
   return run_ps(PSE_DGRAD_ADDPOOL, dz_ps, wpk, nullptr, nullptr, nullptr, io, N, Cout, Cin, H, W, slope, (hipStream_t)stream);
 }
+
+#endif  // PS_TU == -1
