@@ -317,7 +317,7 @@ def pmc_traffic_for(kernel_group: str, B: int, F_: int):
     """HBM bytes per launch of a kernel group from the committed rocprofv3 PMC passes (profiles/*pmc_traffic*.json
     written by tools/pmc_traffic.py with the source hash of the build it profiled) -- null when the sources have
     changed since, or for another batch / width."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     try:
         tj = json.load(open(path))
         if tj.get("csrc_sha256") != kernel_source_hash() or tj.get("batch") != B or tj.get("filters") != F_:
@@ -452,7 +452,7 @@ def main():
         sum_roof = sum(v["t_roof_ms"] * (per[k][0] / n_timed) for k, v in table.items())
         sum_t = sum(v["ms_per_step"] for v in table.values())
         roof = {"bound": d["bound"], "kernel": dom, "groups": dom_groups, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                "frac": round(achieved / peak, 4), "traffic": pmc_traffic_for(dom, B, F_),
+                "frac": round(achieved / peak, 4), "traffic": pmc_traffic_for("+".join(dom_groups), B, F_),
                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_l // n_timed, "timed_on_steps": n_timed,
                 "algorithmic_mb_per_launch": round(nb / 1e6, 1), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
                 "mfma_passes_per_mac": mf_mult,

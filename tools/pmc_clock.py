@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Joins rocprofv3 counter_collection + kernel_trace: per kernel mean duration, effective clock
-(GRBM_GUI_ACTIVE / 8 / duration) and MFMA pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * cycles))."""
+(GRBM_GUI_ACTIVE / 8 / duration) and MFMA pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * cycles)).
+GRBM_GUI_ACTIVE also counts the cycles the graphics block is busy before / after the kernel's own timestamps (dispatch,
+cache write-back), a fixed cost of a few microseconds: for launches under 100 us it inflated the quotient beyond the
+2.4 GHz maximum, so the clock column is printed only from 100 us up ("n/a" below); the MFMA
+utilisation is a ratio of two cycle counts and does not depend on the timestamps."""
 import csv, sys, collections
 d = sys.argv[1]; pre = sys.argv[2]
 tr = {r["Dispatch_Id"]: r for r in csv.DictReader(open(f"{d}/{pre}_kernel_trace.csv"))}
@@ -19,4 +23,5 @@ for k, v in agg.items():
     mf = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", [0])) / max(1, len(v.get("SQ_VALU_MFMA_BUSY_CYCLES", [0])))
     clk = gui / 8 / dur / 1e3 if gui else 0           # GHz
     util = mf / (1024 * gui / 8) if gui else 0
-    print(f"{k:70s} dur={dur:9.1f} us  clock={clk:5.2f} GHz  mfma_util={util:5.2f}")
+    clk_s = f"{clk:5.2f} GHz" if dur >= 100 else "  n/a    "
+    print(f"{k:70s} dur={dur:9.1f} us  clock={clk_s}  mfma_util={util:5.2f}")
