@@ -124,4 +124,6 @@ class MobilenetV3Backbone(BaseModel):
         return x
 
     def to_torchscript(self, file_path=None):
-        raise NotImplementedError("TorchScript export is built for the PoolResnet / Resnet stacks (torchscript.py)")
+        """Scripted inference module through `fdet::mobilenet_forward` (torchscript.ScriptableMobilenet)."""
+        from ..torchscript import to_torchscript
+        return to_torchscript(self, file_path)

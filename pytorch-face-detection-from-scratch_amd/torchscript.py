@@ -9,6 +9,7 @@ into, so the path is exposed to it as dispatcher operators (`torch.library`, nam
     fdet::stack_forward(Tensor x, Tensor[] params, int[] geometry) -> Tensor         the conv stack, eval mode
     fdet::reduce_bounding_boxes(Tensor maps, float pt, float iou, float w, float h) -> (Tensor, Tensor)
     fdet::nms(Tensor boxes, Tensor scores, float iou_threshold) -> Tensor            torchvision.ops.nms semantics
+    fdet::mobilenet_forward(Tensor x, Tensor[] state, str[] names) -> Tensor         MobileNetV3-small backbone + head, eval mode
 
 and `ScriptableDetector` is a small scriptable module (same parameter names as the reference: `conv1`,
 `residual_blocks.k.conv{1,2}`, `out`) whose `forward(x, predict)` calls them.  A saved archive loads with
@@ -60,6 +61,26 @@ def _op_stack_forward(x: torch.Tensor, params: List[torch.Tensor], geo: List[int
     return eng.forward(x.detach(), P, None, save=False)[0]
 
 
+_mb_engines: Dict[tuple, object] = {}
+
+
+def _op_mobilenet_forward(x: torch.Tensor, state: List[torch.Tensor], names: List[str]) -> torch.Tensor:
+    """MobileNetV3-small backbone + head (models/MobilenetV3Backbone.py:49-60), eval mode: `state` / `names` are the
+    module's state_dict (BatchNorm running statistics included); the packed bf16 engine is cached per set of tensors."""
+    from .mobilenetstack import MobileNetStack
+    if len(state) != len(names):
+        raise ValueError("fdet::mobilenet_forward: state and names differ in length")
+    key = tuple((t.data_ptr(), t._version) for t in state)
+    eng = _mb_engines.get(key)
+    if eng is None:
+        if len(_mb_engines) > 8:
+            _mb_engines.clear()
+        eng = MobileNetStack()
+        eng.pack({n: t.detach() for n, t in zip(names, state)})
+        _mb_engines[key] = eng
+    return eng.forward(x.detach())
+
+
 def _op_preprocess(x: torch.Tensor, height: int, width: int) -> torch.Tensor:
     if x.dim() == 3:
         x = x.unsqueeze(0)
@@ -95,7 +116,8 @@ def register_ops() -> None:
     lib.define("stack_forward(Tensor x, Tensor[] params, int[] geometry) -> Tensor")
     lib.define("reduce_bounding_boxes(Tensor maps, float pt, float iou, float w, float h) -> (Tensor, Tensor)")
     lib.define("nms(Tensor boxes, Tensor scores, float iou_threshold) -> Tensor")
-    for name, fn in (("preprocess", _op_preprocess), ("stack_forward", _op_stack_forward),
+    lib.define("mobilenet_forward(Tensor x, Tensor[] state, str[] names) -> Tensor")
+    for name, fn in (("preprocess", _op_preprocess), ("stack_forward", _op_stack_forward), ("mobilenet_forward", _op_mobilenet_forward),
                      ("reduce_bounding_boxes", _op_reduce), ("nms", _op_nms)):
         lib.impl(name, fn, "CUDA")
         lib.impl(name, _no_cpu(name), "CPU")
@@ -165,10 +187,44 @@ class ScriptableDetector(nn.Module):
         return y
 
 
+class ScriptableMobilenet(nn.Module):
+    """`forward(x, predict=tensor(0))` of models.MobilenetV3Backbone in eval mode for `torch.jit.script`.  The module's
+    state (weights and BatchNorm statistics) travels as a tensor-list attribute next to its state_dict names; the
+    arithmetic is `fdet::mobilenet_forward`.  Inference only, like the eager mirror."""
+
+    def __init__(self, model):
+        super().__init__()
+        sd = model.state_dict()
+        self.names: List[str] = list(sd.keys())
+        self.state: List[torch.Tensor] = [t.detach().clone() for t in sd.values()]
+        self.height: int = int(model.input_shape[1])
+        self.width: int = int(model.input_shape[2])
+        self.probability_threshold: float = float(model.reduce_bounding_boxes.probability_threshold)
+        self.iou_threshold: float = float(model.reduce_bounding_boxes.iou_threshold)
+
+    def forward(self, x: torch.Tensor, predict: torch.Tensor = torch.tensor(0)) -> torch.Tensor:
+        want_boxes = bool(predict == 1)
+        if want_boxes:
+            if x.dim() == 3:
+                x = x.unsqueeze(0)
+            # uint8 frames at the model size go straight to the stem (/255 fused there), as in the eager model
+            if not (x.dtype == torch.uint8 and x.size(-2) == self.height and x.size(-1) == self.width):
+                x = torch.ops.fdet.preprocess(x, self.height, self.width)
+        y = torch.ops.fdet.mobilenet_forward(x, self.state, self.names)
+        if want_boxes:
+            rows, counts = torch.ops.fdet.reduce_bounding_boxes(y[0:1], self.probability_threshold, self.iou_threshold,
+                                                                float(self.width), float(self.height))
+            k = int(counts[0])
+            y = rows[0, :k]
+        return y
+
+
 def to_torchscript(model, file_path=None) -> torch.jit.ScriptModule:
     """`torch.jit.script` of the model's inference path; saved to `file_path` when given (Lightning's
     `LightningModule.to_torchscript(file_path)` contract, train_model.py:61)."""
-    scripted = torch.jit.script(ScriptableDetector(model).eval())
+    from .models.MobilenetV3Backbone import MobilenetV3Backbone
+    wrapper = ScriptableMobilenet(model) if isinstance(model, MobilenetV3Backbone) else ScriptableDetector(model)
+    scripted = torch.jit.script(wrapper.eval())
     if file_path is not None:
         torch.jit.save(scripted, str(file_path))
     return scripted

@@ -296,6 +296,31 @@ def test_graphed_predict_equals_eager(golden):
         assert torch.equal(got.cpu(), want.cpu())
 
 
+def test_torchscript_export_matches_eager(golden, tmp_path):
+    """`model.to_torchscript(path)` (the `LightningModule.to_torchscript` contract, train_model.py:61) for the MobileNetV3
+    mirror: the scripted module (operator `fdet::mobilenet_forward`) gives the eager maps and the eager demo-path boxes
+    bit for bit, before and after a torch.jit.save / load round trip."""
+    net = _model(golden("g13_mobilenet_weights"))
+    net.reduce_bounding_boxes.probability_threshold = 0.3
+    path = tmp_path / "mobilenet_scripted.pt"
+    scripted = net.to_torchscript(str(path))
+    loaded = torch.jit.load(str(path))
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(2, 3, 480, 480, generator=g).cuda()
+    frames = torch.randint(0, 256, (2, 3, 480, 480), generator=g, dtype=torch.uint8).cuda()
+    other = torch.randint(0, 256, (3, 300, 400), generator=g, dtype=torch.uint8).cuda()
+    with torch.no_grad():
+        y_e = net(x)
+        det_e = net(frames, torch.tensor(1))
+        det_o = net(other, torch.tensor(1))
+        for sm in (scripted, loaded):
+            assert torch.equal(sm(x), y_e)
+            det_s = sm(frames, torch.tensor(1))
+            assert det_s.shape == det_e.shape and torch.equal(det_s.cpu(), det_e.cpu())
+            det_t = sm(other, torch.tensor(1))
+            assert det_t.shape == det_o.shape and torch.equal(det_t.cpu(), det_o.cpu())
+
+
 def test_training_mode_and_cpu_inputs_fail_loudly(golden):
     from fdet_amd import _native as N
     net = _model(golden("g13_mobilenet_weights"))
