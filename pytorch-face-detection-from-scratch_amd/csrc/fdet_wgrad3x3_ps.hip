@@ -165,7 +165,15 @@ k_wgrad3x3_ps(const PsWgArgs a) {
     const char* xb2 = smem + lane_x + XS(2) * 1024;
     WG_FRAGS(0, 0, zb_, xb0, xb1, xb2)
   }
-  for (; band < l1; ++band) {
+  // Lines that hold only the zero rows under an image (2 of 62 at 60x60, 1 of 16 at 30x30) contribute nothing: they are
+  // walked in a loop of their OWN that rotates the rings and issues the DMA but reads no fragment and runs no MFMA (a
+  // branch around the MFMAs inside one loop made hipcc copy the accumulators every band), then the first step's fragments
+  // of the next real band are read again.
+  int row = l0 - (l0 / a.lpi) * a.lpi;
+  while (band < l1) {
+  const int n_full = row < a.real_lpi ? min(l1 - band, a.real_lpi - row) : 0;
+  row += n_full;
+  for (const int bend = band + n_full; band < bend; ++band) {
     // FL1: every piece issued up to the head of the previous band has landed (x <= band+2, dz <= band+1)
     // else: lines issued two bands ago (x band+1, dz band) have landed; the 8 pieces of the previous band may still fly
     if (FL1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -230,6 +238,26 @@ k_wgrad3x3_ps(const PsWgArgs a) {
     }
     sx = (sx + 1) % XL;
     sz = (sz + 1) % ZL;
+  }
+  if (band < l1 && row >= a.real_lpi) {
+    const int n_zero = min(l1 - band, a.lpi - row);
+    for (const int bend = band + n_zero; band < bend; ++band) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (!(WG_DBG & 1)) WG_ISSUE(band + 3, XS(4), band + 2, (sz + 2) % ZL)
+      sx = (sx + 1) % XL;
+      sz = (sz + 1) % ZL;
+    }
+    row += n_zero;
+    if (row >= a.lpi) row = 0;
+    if (FL1 && band < l1) {                               // the rings hold x <= band+1, dz <= band (the last wait above)
+      const char* zb_ = smem + lane_z + sz * (ZLS * 16);
+      const char* xb0 = smem + lane_x + XS(0) * 1024;
+      const char* xb1 = smem + lane_x + XS(1) * 1024;
+      const char* xb2 = smem + lane_x + XS(2) * 1024;
+      WG_FRAGS(0, 0, zb_, xb0, xb1, xb2)
+    }
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the run-ahead pieces target this workgroup's LDS
 #undef WG_FRAGS
