@@ -78,6 +78,11 @@ class ModelMetaSSD(_Base):
 
     # ------------------------------------------------------------------ epoch hooks (ModelMetaSSD.py:245-327)
     # line for line the hooks of models/ModelMeta.py:241-322 in the reference too: one implementation serves both
+    def to_torchscript(self, file_path=None, method="script", example_inputs=None, **kwargs):
+        """`LightningModule.to_torchscript` (train_model_ssd.py): the scripted inference module of the SSD mirror."""
+        from ..torchscript import to_torchscript
+        return to_torchscript(self.model, file_path)
+
     format_metrics = _YoloMeta.format_metrics
     training_epoch_end = _YoloMeta.training_epoch_end
     validation_epoch_end = _YoloMeta.validation_epoch_end

@@ -86,6 +86,12 @@ class SSD(nn.Module):
     def single_non_max_suppression(self, x):
         return self.reduce_bounding_boxes(x)
 
+    def to_torchscript(self, file_path=None):
+        """Scripted inference module through `fdet::ssd_forward` (torchscript.ScriptableSSD); with predict == 1 it returns
+        the boxes of image 0 (TorchScript cannot return this forward's per-image tuple)."""
+        from ..torchscript import to_torchscript
+        return to_torchscript(self, file_path)
+
     def forward(self, x: torch.Tensor, predict: torch.Tensor = torch.tensor(0)):
         if predict == 1:
             if x.dim() == 3:

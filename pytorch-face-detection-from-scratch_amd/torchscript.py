@@ -10,6 +10,8 @@ into, so the path is exposed to it as dispatcher operators (`torch.library`, nam
     fdet::reduce_bounding_boxes(Tensor maps, float pt, float iou, float w, float h) -> (Tensor, Tensor)
     fdet::nms(Tensor boxes, Tensor scores, float iou_threshold) -> Tensor            torchvision.ops.nms semantics
     fdet::mobilenet_forward(Tensor x, Tensor[] state, str[] names) -> Tensor         MobileNetV3-small backbone + head, eval mode
+    fdet::ssd_forward(Tensor x, Tensor[] params, int filters, int size) -> Tensor    the SSD stack (models/SSD.py:206-255), eval mode
+    fdet::ssd_reduce_bounding_boxes(Tensor y, float pt, float iou, int w, int h, int[] patch_sizes, bool with_priors) -> (Tensor, Tensor)
 
 and `ScriptableDetector` is a small scriptable module (same parameter names as the reference: `conv1`,
 `residual_blocks.k.conv{1,2}`, `out`) whose `forward(x, predict)` calls them.  A saved archive loads with
@@ -81,6 +83,26 @@ def _op_mobilenet_forward(x: torch.Tensor, state: List[torch.Tensor], names: Lis
     return eng.forward(x.detach())
 
 
+_ssd_engines: Dict[Tuple[int, int], object] = {}
+
+
+def _op_ssd_forward(x: torch.Tensor, params: List[torch.Tensor], filters: int, size: int) -> torch.Tensor:
+    """`SSD.forward` up to the prior application (models/SSD.py:206-255), eval mode: (N,3,size,size) f32 -> (N,4774,5)."""
+    from .ssdstack import SSDStack, param_names as ssd_param_names
+    eng = _ssd_engines.get((filters, size))
+    if eng is None:
+        eng = _ssd_engines[(filters, size)] = SSDStack(filters, size)
+    names = ssd_param_names(filters)
+    if len(params) != len(names):
+        raise ValueError(f"fdet::ssd_forward: expected {len(names)} parameter tensors, got {len(params)}")
+    return eng.forward(x.detach(), {n: p.detach() for n, p in zip(names, params)}, None, save=False)[0]
+
+
+def _op_ssd_reduce(y: torch.Tensor, pt: float, iou: float, w: int, h: int, patch_sizes: List[int], with_priors: bool):
+    rows, counts = hp.ssd_reduce_bounding_boxes(y, pt, iou, w, h, tuple(patch_sizes), with_priors)
+    return rows, counts.to(torch.int64)
+
+
 def _op_preprocess(x: torch.Tensor, height: int, width: int) -> torch.Tensor:
     if x.dim() == 3:
         x = x.unsqueeze(0)
@@ -117,7 +139,10 @@ def register_ops() -> None:
     lib.define("reduce_bounding_boxes(Tensor maps, float pt, float iou, float w, float h) -> (Tensor, Tensor)")
     lib.define("nms(Tensor boxes, Tensor scores, float iou_threshold) -> Tensor")
     lib.define("mobilenet_forward(Tensor x, Tensor[] state, str[] names) -> Tensor")
-    for name, fn in (("preprocess", _op_preprocess), ("stack_forward", _op_stack_forward), ("mobilenet_forward", _op_mobilenet_forward),
+    lib.define("ssd_forward(Tensor x, Tensor[] params, int filters, int size) -> Tensor")
+    lib.define("ssd_reduce_bounding_boxes(Tensor y, float pt, float iou, int w, int h, int[] patch_sizes, bool with_priors) -> (Tensor, Tensor)")
+    for name, fn in (("preprocess", _op_preprocess), ("stack_forward", _op_stack_forward), ("mobilenet_forward", _op_mobilenet_forward), ("ssd_forward", _op_ssd_forward),
+                     ("ssd_reduce_bounding_boxes", _op_ssd_reduce),
                      ("reduce_bounding_boxes", _op_reduce), ("nms", _op_nms)):
         lib.impl(name, fn, "CUDA")
         lib.impl(name, _no_cpu(name), "CPU")
@@ -219,11 +244,43 @@ class ScriptableMobilenet(nn.Module):
         return y
 
 
+class ScriptableSSD(nn.Module):
+    """`forward(x, predict=tensor(0))` of models.SSD.SSD (models/SSD.py:206-255) in eval mode for `torch.jit.script`.  With
+    predict == 1 the reference returns a TUPLE of per-image results, which TorchScript cannot mix with the tensor of the
+    other branch: the scripted module returns the boxes of image 0, like the YOLO models' scripted forward."""
+
+    def __init__(self, model):
+        super().__init__()
+        names, params = model.named_stack_params()
+        self.params_list: List[torch.Tensor] = [p.detach().clone() for p in params]
+        self.filters: int = int(model.filters)
+        self.size: int = int(model.input_shape[1])
+        self.patch_sizes: List[int] = [int(v) for v in model.patch_sizes]
+        self.rw: int = int(model.reduce_bounding_boxes.width)
+        self.rh: int = int(model.reduce_bounding_boxes.height)
+        self.probability_threshold: float = float(model.reduce_bounding_boxes.probability_threshold)
+        self.iou_threshold: float = float(model.reduce_bounding_boxes.iou_threshold)
+        self.with_priors: bool = bool(model.reduce_bounding_boxes.with_priors)
+
+    def forward(self, x: torch.Tensor, predict: torch.Tensor = torch.tensor(0)) -> torch.Tensor:
+        want_boxes = bool(predict == 1)
+        if want_boxes:
+            x = torch.ops.fdet.preprocess(x, self.size, self.size)
+        y = torch.ops.fdet.ssd_forward(x, self.params_list, self.filters, self.size)
+        if want_boxes:
+            rows, counts = torch.ops.fdet.ssd_reduce_bounding_boxes(y[0:1], self.probability_threshold, self.iou_threshold,
+                                                                    self.rw, self.rh, self.patch_sizes, self.with_priors)
+            k = int(counts[0])
+            y = rows[0, :k]
+        return y
+
+
 def to_torchscript(model, file_path=None) -> torch.jit.ScriptModule:
     """`torch.jit.script` of the model's inference path; saved to `file_path` when given (Lightning's
     `LightningModule.to_torchscript(file_path)` contract, train_model.py:61)."""
     from .models.MobilenetV3Backbone import MobilenetV3Backbone
-    wrapper = ScriptableMobilenet(model) if isinstance(model, MobilenetV3Backbone) else ScriptableDetector(model)
+    from .models.SSD import SSD
+    wrapper = ScriptableMobilenet(model) if isinstance(model, MobilenetV3Backbone) else (ScriptableSSD(model) if isinstance(model, SSD) else ScriptableDetector(model))
     scripted = torch.jit.script(wrapper.eval())
     if file_path is not None:
         torch.jit.save(scripted, str(file_path))

@@ -257,3 +257,31 @@ def test_reference_modelmeta_ssd_validation_step_and_epoch_hooks(golden, tmp_pat
     assert abs(float(m["loss"]) - float(g["loss"])) <= 1e-4 * float(g["loss"]) and "f1_score" in m
     line = (tmp_path / "ssd.log").read_text()
     assert "training, loss" in line and "validation, loss" in line
+
+
+def test_ssd_torchscript_export_matches_eager(golden, tmp_path):
+    """`model.to_torchscript(path)` / `ModelMetaSSD.to_torchscript` for the SSD mirror (operators `fdet::ssd_forward`,
+    `fdet::ssd_reduce_bounding_boxes`): the scripted module gives the eager (N,4774,5) output bit for bit and, with
+    predict == 1, the eager result of image 0 -- before and after a torch.jit.save / load round trip."""
+    import fdet_amd
+    from fdet_amd.models.SSD import SSD
+    from fdet_amd.models.ModelMetaSSD import ModelMetaSSD
+    from oracle import ssd_model_oracle as SM
+    g = golden("g10_ssd_model")
+    fil, seed = int(g["m_filters"]), int(g["m_seed"])
+    model = SSD(filters=fil, input_shape=(3, SIZE, SIZE), probability_threshold=0.5, iou_threshold=0.3)
+    model.load_state_dict({k: v.clone() for k, v in SM.init_params(fil, seed).items()})
+    model = model.cuda().eval()
+    path = tmp_path / "ssd_scripted.pt"
+    scripted = ModelMetaSSD(model=model, lr=1e-4).to_torchscript(str(path))
+    loaded = torch.jit.load(str(path))
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, SIZE, SIZE, generator=gen).cuda()
+    frames = torch.randint(0, 256, (2, 3, SIZE, SIZE), generator=gen, dtype=torch.uint8).cuda()
+    with torch.no_grad():
+        y_e = model(x)
+        det_e = model(frames, torch.tensor(1))[0]
+        for sm in (scripted, loaded):
+            assert torch.equal(sm(x), y_e)
+            det_s = sm(frames, torch.tensor(1))
+            assert det_s.shape == det_e.shape and torch.equal(det_s.cpu(), det_e.cpu())
