@@ -281,3 +281,35 @@ def test_block_chain_ps_flavour(env, cfg):
         close(dz2_p[k].to_f32(), z2[k].grad)
         assert torch.equal(dz1_p[k].to_f32(), ps.PsTensor.from_f32(dz1_d[k]).to_f32())
         assert torch.equal(dz2_p[k].to_f32(), ps.PsTensor.from_f32(dz2_d[k]).to_f32())
+
+
+@pytest.mark.parametrize("shape", [(3, 60, 60), (5, 30, 30), (2, 12, 56)])
+def test_conv3x3_ps_two_chunk_layers(env, shape):
+    """Layers with 32 channels on the contraction side (two 16-channel chunks per tile instead of four: the woven epilogue
+    then shares BOTH chunks with the next tile): forward 32 -> 64 channels and the data gradient of a 64 -> 32 layer."""
+    hp, ps = env
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * 31 + H + W)
+    # forward, Cin = 32, Cout = 64
+    x = torch.randn(N, 32, H, W, generator=g)
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    nf, nb = hp.packed_sizes(64, 32)
+    wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda")
+    hp.pack_conv3x3_weights(w.cuda(), wf, wb, x3=True)
+    xp = ps.PsTensor.from_f32(x.cuda())
+    yp = ps.PsTensor(N, 64, H, W, "cuda")
+    ps.conv3x3_ps_fwd(xp, wf, b.cuda(), yp, slope=0.2)
+    close(yp.to_f32(), F.leaky_relu(F.conv2d(xp.to_f32().cpu(), w, b, padding=1), 0.2))
+    # data gradient of a layer with Cin = 64, Cout = 32: dx (64 channels) = conv^T(dz (32 channels)) * lrelu'(act)
+    w2 = torch.randn(32, 64, 3, 3, generator=g) * 0.1
+    nf2, nb2 = hp.packed_sizes(32, 64)
+    wf2 = torch.empty(nf2, device="cuda"); wb2 = torch.empty(nb2, device="cuda")
+    hp.pack_conv3x3_weights(w2.cuda(), wf2, wb2, x3=True)
+    dz = torch.randn(N, 32, H, W, generator=g)
+    act = torch.randn(N, 64, H, W, generator=g)
+    dzp = ps.PsTensor.from_f32(dz.cuda()); ap = ps.PsTensor.from_f32(act.cuda())
+    dxp = ps.PsTensor(N, 64, H, W, "cuda")
+    ps.conv3x3_ps_dgrad_act(dzp, wb2, ap, dxp, slope=0.2)
+    ref = F.conv_transpose2d(dzp.to_f32().cpu(), w2, padding=1) * torch.where(act > 0, 1.0, 0.2)
+    close(dxp.to_f32(), ref)
