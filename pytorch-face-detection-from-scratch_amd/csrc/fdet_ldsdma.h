@@ -8,8 +8,10 @@
 // invisible to that pass; it has NO register destination, so none of the hazards of asm loads into registers apply.
 // Ordering is by hand, as cdna_hip_programming.md 5.7 / MI355X_MICROARCH.md item 7 prescribe: the issuing wave's counted
 // `s_waitcnt vmcnt(N)`, then a workgroup barrier, then the ds_read.
-//   * M0 is written in the same statement that uses it; nothing else in these kernels uses M0 (checked in the .s: no
-//     compiler-generated m0 reference), so it is not saved;
+//   * M0 is written in the same statement that uses it.  It is NOT on the clobber list: hipcc treats m0 as a reserved
+//     register ("clobbering them may lead to undefined behaviour"; the generated code is identical with and without the
+//     clobber).  Instead tests/test_asm_audit.py asserts, from the cross-compiled assembly of every kernel that includes
+//     this header, that no compiler-generated instruction reads or writes m0;
 //   * `s_nop 4` covers the SALU-write -> VMEM-read wait states of M0 / the scalar offset / the descriptor;
 //   * compiler-issued loads / stores stay correct beside asm pieces as long as no piece is issued between such a load
 //     and its first use (an OLDER piece only makes the compiler's counted wait stricter).

@@ -3,8 +3,8 @@
 The reference normalises on the host (`img / 255`, datasets/WIDERFace/dataset.py:146) and lets the
 DataLoader collate float32 batches (datamodule.py:162-175): 4 bytes per pixel cross PCIe, 708 MB
 for a (256,3,480,480) batch -- ~11 ms at 63 GB/s, twice the MI355X step time.  Here frames stay
-uint8 until they are on the device: pinned staging buffers, one copy stream, `depth` batches in
-flight, and the /255 (or bilinear Resize + /255 for frames of another size) runs on the device
+uint8 until they are on the device: pinned staging buffers, one copy stream, `depth` slots (3: the slot
+batch i+1 is copied into was last read by step i-2, so its copy never waits for the step that is running), and the /255 (or bilinear Resize + /255 for frames of another size) runs on the device
 right behind the copy (fdet_u8_to_f32_norm / fdet_resize_bilinear_u8_norm).
 """
 from typing import Optional, Tuple
@@ -16,7 +16,7 @@ from .. import hotpath as hp
 
 class U8BatchFeeder:
     def __init__(self, batch_shape: Tuple[int, int, int, int], model_size: Tuple[int, int], device,
-                 target_shape: Optional[Tuple[int, ...]] = None, depth: int = 2):
+                 target_shape: Optional[Tuple[int, ...]] = None, depth: int = 3):
         B, C, H, W = batch_shape
         self.device = torch.device(device)
         self.model_size = (int(model_size[0]), int(model_size[1]))
@@ -54,14 +54,20 @@ class U8BatchFeeder:
             raise RuntimeError("U8BatchFeeder: all slots are in flight; call get() first")
         s = self._slots[self._w]
         s["free"].synchronize()                      # the consumer of this slot's previous batch is done
+        src = s["pin"]
         if frames_u8 is not None:
             if frames_u8.dtype != torch.uint8 or frames_u8.is_cuda:
                 raise TypeError("U8BatchFeeder.submit expects a uint8 CPU tensor")
-            s["pin"].copy_(frames_u8)
+            if frames_u8.is_pinned() and frames_u8.is_contiguous() and tuple(frames_u8.shape) == tuple(s["pin"].shape):
+                # a loader that collates into pinned memory (DataLoader(pin_memory=True)): the DMA engine reads the caller's
+                # buffer directly -- no 177 MB host memcpy into the staging slot.  The slot keeps a reference until it is reused.
+                src = s["src"] = frames_u8
+            else:
+                s["pin"].copy_(frames_u8)
         if targets is not None:
             s["ypin"].copy_(targets)
         with torch.cuda.stream(self.copy_stream):
-            s["u8"].copy_(s["pin"], non_blocking=True)
+            s["u8"].copy_(src, non_blocking=True)
             if s["y"] is not None:
                 s["y"].copy_(s["ypin"], non_blocking=True)
             if tuple(s["u8"].shape[-2:]) == self.model_size:

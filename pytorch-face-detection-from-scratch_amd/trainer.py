@@ -5,8 +5,8 @@ batch, `training_epoch_end`, `validation_step` / `validation_epoch_end` under no
 epoch, and at the end `to_torchscript(path)`.
 
 Batches are host tensors as a DataLoader yields them: (x, y, gt_bbxs) with x either uint8 frames (B,3,H,W) -- fed
-through `U8BatchFeeder` (pinned staging, copy stream, /255 or bilinear resize on the device, two batches in
-flight) -- or float32 in [0,1]; y the encoded targets (B,5,S,S).  The optimisation step is `fused_train_step` (forward +
+through `U8BatchFeeder` (pinned staging or the loader's own pinned tensors, copy stream, /255 or bilinear resize on the
+device, three slots: the copy of batch i+1 runs under step i) -- or float32 in [0,1]; y the encoded targets (B,5,S,S).  The optimisation step is `fused_train_step` (forward +
 YoloLoss + backward + all-reduce + Adam as direct kernel launches); its step outputs (loss, total_iou, total_recall,
 total_precision) have the meaning of `ModelMeta.training_step`'s (models/ModelMeta.py:115-227).
 """
@@ -44,12 +44,13 @@ def _epoch(model_meta, batches, train: bool, feeder_cache: dict, on_step: Option
     step = 0
     while pending is not None:
         kind, payload = pending
-        nxt = next(it, None)
-        following = stage(nxt) if nxt is not None else None          # the next batch's copy overlaps this step
         if kind == "feeder":
             x_d, y_d, tok = payload.get()
         else:
             (x_d, y_d), tok = payload, None
+        # the step of THIS batch is enqueued first; only then is the next batch staged.  Staging may block the host on the
+        # slot's previous consumer (feed.py: `free.synchronize()`), and with the step already queued the GPU keeps working
+        # through that wait; with 3 slots the reused slot belongs to step i-2, which has normally finished.
         if train:
             model.train()
             lsum, y_hat, tot = model_meta.fused_train_step(x_d, y_d, with_metrics=True)
@@ -60,6 +61,8 @@ def _epoch(model_meta, batches, train: bool, feeder_cache: dict, on_step: Option
                 out = model_meta.validation_step((x_d, y_d, None), step)
         if tok is not None:
             U8BatchFeeder.release(tok)
+        nxt = next(it, None)
+        following = stage(nxt) if nxt is not None else None          # the next batch's copy overlaps this step
         outs.append(out)
         if on_step is not None:
             on_step(step, train, out)

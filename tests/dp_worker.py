@@ -38,9 +38,13 @@ def run_rank(rank, world, F_, b_local, steps, live_dropout, param_seed):
         model.set_dropout_masks({k: v[lo:hi] for k, v in masks.items()})
     xs, ys = x[lo:hi].cuda(), y[lo:hi].cuda()
     losses = []
-    for _ in range(steps):
+    for s_ in range(steps):
         lsum, _, _ = mm.fused_train_step(xs, ys)
         losses.append(float(lsum))
+        if s_ == 0:
+            # the step-1 gradient: every rank started from rank 0's parameters and the same masks, so the all-reduced
+            # gradient may differ from the single-process one by summation order only
+            run_rank.grad_step1 = mm.opt._space().grad.cpu().clone()
     sp = mm.opt._space()
     return ({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, sp.grad.cpu().clone(), losses,
             mm._reducer.enabled)
@@ -96,6 +100,7 @@ if __name__ == "__main__":
     if not ssd:                                               # YOLO: per-rank loss sums add up; SSD: every rank holds the batch loss
         dist.all_reduce(tot)
     if rank == 0:
-        torch.save({"params": params, "grad": grad, "loss_sum": tot.tolist()}, out)
+        torch.save({"params": params, "grad": grad, "loss_sum": tot.tolist(),
+                    "grad_step1": None if ssd else run_rank.grad_step1}, out)
     dist.barrier()
     dist.destroy_process_group()

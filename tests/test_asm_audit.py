@@ -5,6 +5,7 @@ in-flight destination on any control-flow path -- for EVERY built instantiation 
 against a compiler or code change breaking it silently.  (Round 3: the weight-gradient pipeline retires both register
 sets before its band ends, the stem forward walks its rows in pairs without a mid-loop exit; both were findings before.)"""
 import importlib.util
+import re
 import os
 import shutil
 import subprocess
@@ -25,7 +26,7 @@ KERNELS = {
     "fdet_stem_x3.hip": ["_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb0E", "_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb1E",
                          "_ZN12_GLOBAL__N_120k_stem_wgrad_x3_pipe"],
 }
-# The PS kernels (fdet_conv3x3_ps.hip, fdet_wgrad3x3_ps.hip) issue LDS-DMA from asm: no register destination, nothing to audit.
+# The PS kernels issue LDS-DMA from asm (no register destination); their hand-counted waits are audited further down.
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
@@ -45,3 +46,61 @@ def test_no_instruction_touches_in_flight_asm_loads(src, tmp_path):
     import re
     built = set(re.findall(r"^(_ZN12_GLOBAL__N_1\d+k_(?:wgrad3x3_x3_pipe|stem_fwd_x3_pipe|stem_wgrad_x3_pipe)\w*):", open(out).read(), re.M))
     assert built and all(any(b.startswith(k) for k in KERNELS[src]) for b in built), built
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The LDS-DMA kernels (fdet_conv3x3_ps.hip: 8 instantiations, fdet_wgrad3x3_ps.hip, fdet_chain_x3.hip): asm pieces have no
+# register destination, but the waits that open an LDS buffer are `s_waitcnt vmcnt(K)` with K a HAND COUNT of
+# compiler-issued stores / prefetch loads.  tools/audit_vmcnt.py proves from the cross-compiled assembly that every K is
+# backed by a run of at least K vector-memory operations behind the nearest DMA piece and that no other run length can
+# reach the wait (a merged, dropped or duplicated store changes a run length).
+PS_CONV_TUS = list(range(8))           # PS_TU = 2 * mode + (WP == 64): FWD_FULL, DGRAD_ACT, FWD_POOL, DGRAD_ADDPOOL x {32, 64}
+VM_KERNELS = {
+    # k_wgrad3x3_ps<WP, FL1 = true> (the default one-band flight) waits with vmcnt(0) only: listed so that a future counted
+    # wait is audited.  FL1 = false counts asm DMA pieces themselves (volatile asm: the compiler cannot merge or drop them).
+    "fdet_wgrad3x3_ps.hip": ["_ZN12_GLOBAL__N_113k_wgrad3x3_psILi64ELb1E", "_ZN12_GLOBAL__N_113k_wgrad3x3_psILi32ELb1E",
+                             "_ZN12_GLOBAL__N_113k_wgrad3x3_psILi16ELb1E"],
+    "fdet_chain_x3.hip": ["_ZN12_GLOBAL__N_116k_block_chain_psILb0E", "_ZN12_GLOBAL__N_116k_block_chain_psILb1E",
+                          "_ZN12_GLOBAL__N_116k_block_chain_x3ILb0E"],
+}
+
+
+def _compile_s(args):
+    src, out, defs = args
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                    "-S", "--cuda-device-only"] + defs + [os.path.join(CSRC, src), "-o", out], check=True, capture_output=True, timeout=1200)
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_hand_counted_vmcnt_waits_of_the_lds_dma_kernels(tmp_path):
+    from concurrent.futures import ThreadPoolExecutor
+    spec = importlib.util.spec_from_file_location("audit_vmcnt", os.path.join(ROOT, "tools", "audit_vmcnt.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    jobs = [("fdet_conv3x3_ps.hip", str(tmp_path / f"ps{tu}.s"), [f"-DPS_TU={tu}"]) for tu in PS_CONV_TUS]
+    jobs += [(src, str(tmp_path / (src + ".s")), []) for src in VM_KERNELS]
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        outs = list(ex.map(_compile_s, jobs))
+    todo = [("_ZN12_GLOBAL__N_112k_conv3x3_ps", o) for o in outs[:len(PS_CONV_TUS)]]
+    for src, o in zip(VM_KERNELS, outs[len(PS_CONV_TUS):]):
+        todo += [(k, o) for k in VM_KERNELS[src]]
+    n_waits = 0
+    for k, o in todo:
+        res, ndma = mod.audit(k, o)
+        assert ndma > 0, f"{k}: no LDS-DMA pieces found (kernel renamed?)"
+        bad = mod.check(res)
+        print(f"{k} ({os.path.basename(o)}): {ndma} DMA pieces, {len(res)} hand-counted waits: {sorted({K for _, K, _ in res})}")
+        assert not bad, f"{k} ({os.path.basename(o)}): {bad[:3]}"
+        n_waits += len(res)
+    assert n_waits >= 40                                   # the conv instantiations alone hold ~60 counted waits
+    # every DMA piece overwrites M0 without declaring it (fdet_ldsdma.h): no compiler-generated instruction may read or write it
+    for o in outs:
+        inasm = False
+        for ln in open(o):
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                inasm = True
+            elif t.startswith(";;#ASMEND"):
+                inasm = False
+            elif not inasm and t and not t.startswith((";", ".")) and re.search(r"\bm0\b", t.split(";")[0]):
+                raise AssertionError(f"{os.path.basename(o)}: compiler-generated use of m0: {t}")

@@ -47,10 +47,15 @@ def test_two_ranks_fused_train_step_equals_single_process(tmp_path, live_dropout
     assert not enabled
     for a, b in zip(got["loss_sum"], losses):
         assert abs(a - b) <= 1e-5 * abs(b), (got["loss_sum"], losses)
+    # STEP 1 (SURVEY.md 8e's oracle): identical parameters and masks on both sides, the forward is batch-invariant bit for
+    # bit, so the all-reduced gradient differs from the single-process one by fp32 summation order only (2 + 2 images and
+    # an all-reduce against 4; the weight-gradient slabs cut the batch at other places)
+    g1_ref, g1_got = dp_worker.run_rank.grad_step1, got["grad_step1"]
+    g1max = float(g1_ref.abs().max())
+    assert float((g1_got - g1_ref).abs().max()) <= 2e-5 * g1max, float((g1_got - g1_ref).abs().max()) / g1max
     g_ref, g_got = grad, got["grad"]
     gmax = float(g_ref.abs().max())
-    # last step's all-reduced flat gradient, at the north star's 1e-4: the two runs sum the images in a different order
-    # (2 + 2 and an all-reduce vs 4), and step 2 starts from parameters that already differ where Adam's first update
+    # step 2's all-reduced flat gradient, at the north star's 1e-4 only: step 2 starts from parameters that already differ where Adam's first update
     # flipped on a ~0 gradient (below)
     assert float((g_got - g_ref).abs().max()) <= 1e-4 * gmax
     lr = 1e-4

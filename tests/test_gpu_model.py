@@ -315,6 +315,75 @@ def test_reference_f16_train_step_reaches_bf16x3_backward(fd, golden):
         assert float((d > 1e-6).float().mean()) < 0.02, n
 
 
+def test_reference_f64_train_step_through_the_pre_split_kernels(fd, golden):
+    """g15 = one train step of the REFERENCE PoolResnet at the headline width (filters 64, B=2; tools/make_goldens_r4.py):
+    the reference-produced numbers that reach `k_conv3x3_ps`, `k_wgrad3x3_ps`, `k_block_chain_ps` -- the whole timed path
+    (the engine must be on its PS path).  Forward and loss at 1e-4 (north star); every gradient tensor in the L2 sense and
+    per entry on the fixture's 4096-entry sample; parameters after Adam."""
+    from fdet_amd.models import ModelMeta
+    from fdet_amd.models.PoolResnet import PoolResnet
+    g = golden("g15_poolresnet_F64")
+    torch.manual_seed(int(g["param_seed"]))
+    model = PoolResnet(filters=64, input_shape=(3, 480, 480), num_of_patches=10, num_of_residual_blocks=10)
+    names_ref = [str(n) for n in g["names"]]
+    sd = model.state_dict()
+    assert list(sd.keys()) == names_ref
+    for n, s in zip(names_ref, g["param_sum"].tolist()):
+        assert float(sd[n].double().sum()) == s, n          # same seed -> the reference constructor's parameters
+    model = model.cuda().train()
+    eng = model.engine
+    assert eng.x3 and eng.ps and eng._ps_block(0) and eng._ps_block(1) and eng._ps_chain(2)
+    mm = ModelMeta(model=model, lr=1e-4)
+    mm.configure_optimizers()
+    x_u8 = _redraw_u8(2, 480, int(g["x_seed"]), g["x_sum"])
+    assert torch.equal(x_u8[:, :, ::97, ::89], g["x_probe"])
+    model.set_dropout_masks({k[len("mask/"):]: v for k, v in g.items() if k.startswith("mask/")})
+    lsum, y_hat, _ = mm.fused_train_step((x_u8.float() / 255.0).cuda(), g["y"].cuda())
+    assert torch.allclose(y_hat.cpu(), g["y_train"], atol=1e-4)
+    assert abs(float(lsum) - float(g["loss"])) <= 1e-4 * max(1.0, float(g["loss"]))
+    sp = mm.opt.space
+    names, _ = model.named_stack_params()
+    assert list(names) == names_ref
+    for i, n in enumerate(names):
+        got = sp.view(sp.grad, i).detach().cpu().double().reshape(-1)
+        idx = g["idx/" + n].long()
+        ref = g["grad/" + n].double()
+        scale = float(g["grad_absmax"][i])
+        # whole-tensor check through the stored norm; the sample bounds single entries (max-pool routing of near-tied
+        # windows moves single entries, see test_gradient_entries_differ_only_through_pool_routing)
+        assert abs(float(got.norm()) - float(g["grad_norm"][i])) <= 2e-3 * float(g["grad_norm"][i]), n
+        rel_l2 = float((got[idx] - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert rel_l2 <= 2e-3, (n, rel_l2)
+        assert float((got[idx] - ref).abs().max()) <= 2e-2 * scale, n
+    for n, p in model.named_parameters():
+        d = (p.detach().cpu().reshape(-1)[g["idx/" + n].long()] - g["param_after/" + n]).abs()
+        assert float(d.max()) <= 2.1e-4, n
+        assert float((d > 1e-6).float().mean()) < 0.02, n
+
+
+def test_trained_medium_archive_demo_path(fd, golden):
+    """g16: demo_model.py:11-21 with the shipped MEDIUM PoolResnet weights (filters 64: the PS inference kernels), thresholds
+    0.7 / 0.01: conv-stack output at 1e-4, boxes of image 0 exact."""
+    from fdet_amd.models.PoolResnet import PoolResnet
+    g = golden("g16_trained_medium")
+    images = golden("g6_trained_small")["images"]
+    P = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    model = PoolResnet(filters=64, input_shape=(3, 480, 480), num_of_patches=10, probability_threshold=0.7, iou_threshold=0.01)
+    model = _load(model, P).eval()
+    assert model.engine.ps
+    for n in range(images.shape[0]):
+        u8 = images[n].cuda()
+        with torch.no_grad():
+            y = model(torch.stack([u8, u8]).float() / 255.0)
+            det = model(torch.stack([u8, u8]), predict=torch.tensor(1))
+        assert torch.allclose(y[0].cpu(), g["y"][n], atol=1e-4)
+        nd = int(g["ndets"][n])
+        assert det.shape == (nd, 5)
+        if nd:
+            assert torch.allclose(det[:, 0].cpu(), g["dets"][n, :nd, 0], atol=1e-4)
+            assert torch.equal(det[:, 1:].cpu(), g["dets"][n, :nd, 1:])
+
+
 def _oracle_blocks(spec, P, x, masks):
     """The oracle's forward (oracle.model_forward's own ops) with every block's intermediates kept:
     k -> (c, e, a, block input, pooled?)."""

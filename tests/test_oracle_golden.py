@@ -250,6 +250,58 @@ def test_reference_poolresnet_f16_train_step(golden):
         assert torch.allclose(G[k], ref, atol=1e-5 + 1e-4 * float(ref.abs().max()), rtol=1e-4), k
 
 
+def _g15_inputs(g):
+    """Inputs of the F=64 fixtures (tools/make_goldens_r4.py) rebuilt from their seeds, checked against the stored sums."""
+    x_u8 = _redraw_u8(2, 480, int(g["x_seed"]), g["x_sum"])
+    assert torch.equal(x_u8[:, :, ::97, ::89], g["x_probe"])
+    spec = O.poolresnet_spec(64, (3, 480, 480), 10)
+    P = O.init_params(spec, seed=int(g["param_seed"]))
+    names = [str(n) for n in g["names"]]
+    assert names == list(P.keys())
+    for n, s in zip(names, g["param_sum"].tolist()):
+        assert float(P[n].double().sum()) == s, n             # the seed reproduces the reference constructor's values
+    masks = {k[len("mask/"):]: v for k, v in g.items() if k.startswith("mask/")}
+    return spec, P, names, x_u8.float() / 255.0, masks
+
+
+def test_reference_poolresnet_f64_train_step(golden):
+    """g15: the reference PoolResnet at the HEADLINE width (filters 64), one train step at B=2 -- pins the oracle at the
+    width every timed kernel runs (forward, loss, every gradient tensor's norm and a 4096-entry sample, Adam)."""
+    g = golden("g15_poolresnet_F64")
+    spec, P, names, x, masks = _g15_inputs(g)
+    state = {"exp_avg": {k: torch.zeros_like(v) for k, v in P.items()},
+             "exp_avg_sq": {k: torch.zeros_like(v) for k, v in P.items()}}
+    loss, y_train, G = O.train_step(spec, P, state, 1, x, g["y"], masks)
+    assert torch.allclose(y_train, g["y_train"], atol=1e-5, rtol=1e-5)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * max(1.0, float(g["loss"]))
+    for i, k in enumerate(names):
+        idx = g["idx/" + k].long()
+        ref = g["grad/" + k]
+        assert torch.allclose(G[k].reshape(-1)[idx], ref, atol=1e-5 + 1e-4 * float(g["grad_absmax"][i]), rtol=1e-4), k
+        assert abs(float(G[k].double().norm()) - float(g["grad_norm"][i])) <= 1e-4 * float(g["grad_norm"][i]), k
+        d = (P[k].reshape(-1)[idx] - g["param_after/" + k]).abs()
+        assert float(d.max()) <= 2.1e-4, k
+        assert float((d > 1e-6).float().mean()) < 0.02, k
+
+
+def test_trained_medium_archive(golden):
+    """g16: the medium archive (demo_model.py:11-13) through the oracle: conv-stack output and the demo path's boxes."""
+    g = golden("g16_trained_medium")
+    images = golden("g6_trained_small")["images"]
+    P = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    spec = O.poolresnet_spec(64, (3, 480, 480), 10)
+    for n in range(images.shape[0]):
+        u8 = images[n]
+        with torch.no_grad():
+            y = O.model_forward(spec, P, torch.stack([u8, u8]).float() / 255.0, None)
+        assert torch.allclose(y[0], g["y"][n], atol=1e-5)
+        det = O.predict_image0(spec, P, torch.stack([u8, u8]), 0.7, 0.01)
+        nd = int(g["ndets"][n])
+        assert det.shape[0] == nd
+        assert torch.allclose(det[:, 0], g["dets"][n, :nd, 0], atol=1e-4)
+        assert torch.equal(det[:, 1:], g["dets"][n, :nd, 1:])
+
+
 def test_mobilenet_fixture_and_oracle_shapes(golden):
     """g13 = the parameter tensors of the reference's shipped MobileNetV3 archive (raw storage bytes,
     tools/make_goldens_mobilenet.py).  PARITY UNPINNED for this model: no reference output exists (timm absent, archive not
