@@ -51,6 +51,14 @@ SYMBOL_OF = {   # timer group -> kernel symbol (template instantiation) it launc
 }
 
 
+_T0 = time.perf_counter()
+
+
+def _log(msg: str) -> None:
+    """progress on stderr (the driver reads stdout's one JSON line; a long leg must not look hung)"""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def self_launch(args) -> int:
     """Start N fresh rank processes (one per GPU) as a child `torch.distributed.run`; nothing in THIS
     process has initialised the GPU (device_count() does not on this image)."""
@@ -91,37 +99,55 @@ def cpu_model_name() -> str:
     return "unknown"
 
 
+def effective_cpus() -> int:
+    from fdet_amd.hostinfo import effective_cpus as f
+    return f()
+
+
 def cpu_baseline(filters, size, S, sample_bs, steps, frames=100, warm=20):
     """The CPU oracle (a port of the reference's CPU path on stock torch ops) timed on this box's host cores on
     a bounded sample of the same workload: (1) the headline training step, (2) BASELINE.json config 1, the
     reference's demo path (demo_model.py:17-21: uint8 frame stacked twice -> /255 -> conv stack -> decode -> NMS).
-    BASELINE.md section 3 plans `torch.set_num_threads(os.cpu_count())`: that run is `value`; the 16-thread run of the
-    earlier rounds is kept beside it (`threads16`), because a 64-image batch does not scale to 256 hardware threads."""
+    BASELINE.md section 3 plans `torch.set_num_threads(os.cpu_count())`: `value` is the run on every core this process is
+    GRANTED (effective_cpus(): affinity and cgroup quota; os.cpu_count() itself is reported as host_logical_cpus); the
+    16-thread run of the earlier rounds is kept beside it (`threads16`).  A leg whose warm-up step alone exceeds its time
+    budget is abandoned and reported as such instead of stalling the bench."""
     import oracle as O
-    ncpu = os.cpu_count() or 1
+    ncpu = effective_cpus()
     spec = O.poolresnet_spec(filters, (3, size, size), S)
     g = torch.Generator().manual_seed(0)
     x = torch.rand(sample_bs, 3, size, size, generator=g)
     y = torch.stack([O.encode_targets(b, (size, size), S) for b in O.synthetic_boxes(sample_bs, size, seed=1)])
     masks = O.make_dropout_masks(spec, sample_bs, seed=2)
 
-    def train_leg(threads, n_steps):
+    def train_leg(threads, n_steps, budget_s=15.0):
+        """n_steps timed steps, cut short once `budget_s` seconds of CPU work are spent (at least one step)"""
         torch.set_num_threads(threads)
         P = O.init_params(spec, seed=0)
         state = {"exp_avg": {k: torch.zeros_like(v) for k, v in P.items()},
                  "exp_avg_sq": {k: torch.zeros_like(v) for k, v in P.items()}}
-        O.train_step(spec, P, state, 1, x, y, masks)                   # warm-up
         t0 = time.perf_counter()
+        O.train_step(spec, P, state, 1, x, y, masks)                   # warm-up
+        if time.perf_counter() - t0 > budget_s:
+            dtw = time.perf_counter() - t0
+            _log(f"cpu_baseline: {threads} threads: the warm-up step took {dtw:.1f} s, leg abandoned")
+            return sample_bs / dtw, dtw, 0
+        t0 = time.perf_counter()
+        done = 0
         for s in range(n_steps):
             O.train_step(spec, P, state, 2 + s, x, y, masks)
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
         dt = time.perf_counter() - t0
-        return sample_bs * n_steps / dt, dt
+        _log(f"cpu_baseline: {threads} threads, {done} steps at batch {sample_bs} in {dt:.1f} s")
+        return sample_bs * done / dt, dt, done
 
-    v16, dt16 = train_leg(min(16, ncpu), steps)
+    v16, dt16, n16 = train_leg(min(16, ncpu), steps)
     if ncpu > 16:
-        vall, dtall = train_leg(ncpu, max(3, steps // 2))
+        vall, dtall, nall = train_leg(ncpu, max(3, steps // 2))
     else:
-        vall, dtall = v16, dt16
+        vall, dtall, nall = v16, dt16, n16
     # config 1: PoolResnet F=64 S=10 eval, thresholds 0.7 / 0.01 (the shipped archives' frozen values); a two-frame
     # forward is latency-bound on the host: timed at the faster of the two thread counts' natural choice (16)
     threads = min(16, ncpu)
@@ -137,11 +163,11 @@ def cpu_baseline(filters, size, S, sample_bs, steps, frames=100, warm=20):
             O.predict_image0(spec, P1, pair, 0.7, 0.01)
         dt1 = (time.perf_counter() - t1) / frames
     return {"value": round(vall, 2), "unit": "imgs/s", "cores": ncpu, "kind": "port",
-            "host_logical_cpus": ncpu, "threads_used": ncpu, "cpu_model": cpu_model_name(),
-            "sample": f"{max(3, steps // 2) if ncpu > 16 else steps} training steps (fwd+loss+bwd+Adam) at batch {sample_bs}, "
+            "host_logical_cpus": os.cpu_count(), "threads_used": ncpu, "cpu_model": cpu_model_name(),
+            "sample": f"{nall} training steps (fwd+loss+bwd+Adam) at batch {sample_bs}, "
                       f"oracle.train_step, torch CPU fp32, torch.set_num_threads({ncpu}), {dtall:.1f} s",
             "threads16": {"value": round(v16, 2), "unit": "imgs/s", "cores": min(16, ncpu),
-                          "sample": f"{steps} training steps at batch {sample_bs}, {min(16, ncpu)} threads, {dt16:.1f} s"},
+                          "sample": f"{n16} training steps at batch {sample_bs}, {min(16, ncpu)} threads, {dt16:.1f} s"},
             "config1_demo_path": {"ms_per_frame": round(dt1 * 1e3, 3), "fps": round(1.0 / dt1, 1), "cores": threads,
                                   "sample": f"{frames} frames after {warm} warm-up, oracle.predict_image0 (2 stacked uint8 "
                                             "480x480 frames -> /255 -> PoolResnet-medium -> decode -> NMS of image 0, "
@@ -164,17 +190,20 @@ def feed_legs(mm, model, B, size, S, device, steps):
     from fdet_amd import trainer
     out = {}
     x, y, _ = synth_batch(B, size, S, seed=100, device=device)
+    _log("feed legs: step with metrics")
     dt, _ = _time_steps(lambda: mm.fused_train_step(x, y, with_metrics=True), 2, steps)
     out["step_with_metrics_ms"] = round(dt * 1e3, 3)
     dt0, _ = _time_steps(lambda: mm.fused_train_step(x, y), 2, steps)
     out["step_without_metrics_ms_same_loop"] = round(dt0 * 1e3, 3)
     del x
     g = torch.Generator().manual_seed(1)
+    _log("feed legs: PCIe-inclusive step")
     feeder = U8BatchFeeder((B, 3, size, size), (size, size), device, target_shape=(B, 5, S, S), depth=3)
     y_host = y.cpu()
+    frames = torch.randint(0, 256, (B, 3, size, size), dtype=torch.uint8, generator=g)
     for i in range(3):                                     # the three pinned slots are filled once (a loader decodes into them)
         pin, ypin = feeder.host_buffers()
-        pin.copy_(torch.randint(0, 256, (B, 3, size, size), dtype=torch.uint8, generator=g)); ypin.copy_(y_host)
+        pin.copy_(frames.roll(i, 0)); ypin.copy_(y_host)
         feeder.submit()
         xf, yf, tok = feeder.get(); mm.fused_train_step(xf, yf); feeder.release(tok)
 
@@ -190,9 +219,10 @@ def feed_legs(mm, model, B, size, S, device, steps):
     del feeder
     # trainer.fit over host batches in pinned memory (what DataLoader(pin_memory=True) yields)
     nb = max(4, steps)
+    _log("feed legs: trainer.fit")
     batches = []
     for i in range(2):
-        batches.append((torch.randint(0, 256, (B, 3, size, size), dtype=torch.uint8, generator=g).pin_memory(), y_host, None))
+        batches.append((frames.roll(i + 1, 0).pin_memory(), y_host, None))
     seq = [batches[i % 2] for i in range(nb)]
     marks = []
 
@@ -451,6 +481,8 @@ def main():
     from fdet_amd.models import ModelMeta
     from fdet_amd.models.PoolResnet import PoolResnet
     from fdet_amd.convstack import KernelTimer
+    from fdet_amd.hostinfo import limit_host_threads
+    limit_host_threads()                                   # the box grants 16 of its 256 logical CPUs (hostinfo.py)
 
     size, S, B, F_ = 480, 10, args.batch, args.filters
     torch.manual_seed(0)                                   # train_model.py:13 (ranks are synchronised to rank 0's weights anyway)
@@ -582,14 +614,19 @@ def main():
                 "frac_of_max_floor_single_count": round(max(gf / (mf_peak * 1e3) * 1e3, gb / PEAK_HBM_GBS * 1e3) / ms, 4)}
         if world == 1 and not args.no_feed:
             out.update(feed_legs(mm, model, B, size, S, device, steps=min(args.steps, 10)))
+        _log(f"headline timed: {ms:.3f} ms/step")
         if world == 1 and not args.no_inference:
+            _log("inference leg")
             out["inference"] = infer_bench(model, size, device)
         if world == 1 and not args.no_configs:
             del x, y
             torch.cuda.empty_cache()
+            _log("configs 3 / 4 / 5")
             out["configs"] = extra_configs(device)
         if world == 1 and not args.no_cpu_baseline:
+            _log("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(F_, size, S, sample_bs=64, steps=20)
+        _log("done")
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

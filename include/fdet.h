@@ -444,6 +444,22 @@ int fdet_head_bwd(const float* x, const float* drop_scale, const float* w, const
                   const float* dy, float* dx, float* dW, float* db, void* ws, size_t ws_bytes,
                   int N, int F, int H, int W, int k, int pad, void* stream);
 
+/* Training head fused with the loss (round 4): ONE launch sequence for what models/PoolResnet.py:100-102 +
+ * losses/YoloLoss.py:4-44 (called per image and summed, models/ModelMeta.py:173-176) + their autograd compute:
+ *   y = sigmoid(conv(x * drop_scale, w) + bias);  loss_per_image[n] = yolo_loss(y[n], gt[n]);  loss_sum = sum_n;
+ *   dx = d loss_sum / d x (includes drop_scale),  dW [5,F,k,k],  db [5].
+ * Equivalent to fdet_head_fwd + fdet_yolo_loss_fwd_bwd(grad_scale 1) + fdet_head_bwd; loss_per_image / loss_sum are
+ * bit-identical to that sequence GIVEN y, y itself is computed in bf16x3 arithmetic (~1e-5 of the fp32 head).
+ * Supported geometry (fdet_head_loss_fused_supported): F = 64, k = 6, pad = 0, maps of at most 15x15 (PoolResnet).
+ * ws: fdet_head_loss_fused_ws_bytes() bytes, 16-byte aligned; its LAST 64 bytes are a ticket counter that must be
+ * zero at the first call (the kernel leaves it zero); do not share ws between launches that may overlap. */
+int fdet_head_loss_fused_supported(int F, int H, int W, int k, int pad);
+size_t fdet_head_loss_fused_ws_bytes(int N, int F, int H, int W, int k, int pad);
+int fdet_head_loss_fused(const float* x, const float* drop_scale, const float* w, const float* bias,
+                         const float* gt, float* y, float* loss_per_image, float* loss_sum, float* dx,
+                         float* dW, float* db, void* ws, size_t ws_bytes, int N, int F, int H, int W, int k,
+                         int pad, void* stream);
+
 /* Dropout2d scale factors: out[i] = (u_i >= p) ? 1/(1-p) : 0 with u from a counter-based
  * generator keyed by (seed, offset+i).  Replaces nn.Dropout2d's per-(n,c) Bernoulli draw
  * (models/PoolResnet.py:31,69).  The stream differs from ATen's Philox usage, so parity

@@ -119,6 +119,9 @@ SIGNATURES = {
     "fdet_head_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_head_bwd_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "fdet_head_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _P]),
+    "fdet_head_loss_fused_supported": (_I, [_I, _I, _I, _I, _I]),
+    "fdet_head_loss_fused_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
+    "fdet_head_loss_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_dropout_scales": (_I, [_P, _SZ, _F, _U64, _U64, _P]),
     "fdet_dropout_scales_layers": (_I, [_P, _I, _I, _P, _P, _U64, _U64, _U64, _P]),
 }

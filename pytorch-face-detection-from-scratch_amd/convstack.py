@@ -160,6 +160,16 @@ class ConvStack:
         # and their gradients live as bf16 hi|lo units, staged by LDS-DMA (FDET_PS=0: the fp32-I/O kernels of round 2)
         self.ps = self.pool_fusion and geo.filters == 64 and os.environ.get("FDET_PS", "1") != "0"
         self._ps_pool: Dict[tuple, list] = {}
+        # training head fused with the loss (fdet_head_loss_fused: forward + yolo_loss + their gradients in one kernel on
+        # the matrix cores); FDET_HEAD_FUSED=0 keeps the separate head_fwd / yolo_loss / head_bwd launches
+        self.head_fused = self.x3 and os.environ.get("FDET_HEAD_FUSED", "1") != "0"
+        self._zero_ws: Dict[str, torch.Tensor] = {}
+
+    def head_loss_fusable(self) -> bool:
+        """The fused training head (forward + loss + backward of the head in one launch) covers this geometry."""
+        g = self.geo
+        hl = self.lv[-1][0] // self.lv[-1][1] if self.lv else self.h0
+        return self.head_fused and hp.head_loss_fused_supported(g.filters, hl, hl, g.head_k, g.head_p)
 
     def _t(self, kind: str, N: int, h: int, flops: float = 0.0, nbytes: float = 0.0):
         if self.timer is None:
@@ -253,10 +263,13 @@ class ConvStack:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], masks: Optional[Dict[str, torch.Tensor]] = None,
-                save: bool = False):
+                save: bool = False, loss_targets: Optional[torch.Tensor] = None, G: Optional[Dict[str, torch.Tensor]] = None):
         """x (N,C,H,W) f32 on the GPU -> y (N,5,S,S).  masks: per-(n,c) dropout scales
         {"residual_blocks.k": (N,F), "head": (N,F)} or None (eval).  save=True keeps what
-        backward needs and returns it as the second value."""
+        backward needs and returns it as the second value.
+        loss_targets (N,5,S,S) + G (gradient views): the head runs FUSED with yolo_loss and its own backward
+        (head_loss_fusable()): saved["loss"] = (loss_per_image, loss_sum), G["out.*"] are written, and backward() is
+        called with dy=None."""
         g = self.geo
         if x.dim() != 4 or tuple(x.shape[1:]) != (g.in_ch, g.H, g.W):
             raise ValueError(f"expected input (N,{g.in_ch},{g.H},{g.W}), got {tuple(x.shape)}")
@@ -368,8 +381,27 @@ class ConvStack:
                 saved["blocks"].append((h, a, c))
             h = out
         y = torch.empty(N, 5, g.S, g.S, dtype=F32, device=dev)
-        with self._t("head_fwd", N, h.shape[2], 2.0 * N * 5 * F_ * g.head_k ** 2 * g.S ** 2, self._act_bytes(N, h.shape[2], 1)):
-            hp.head_fwd(h, masks["head"] if masks is not None else None, P["out.weight"], P["out.bias"], y, g.head_k, g.head_p)
+        if loss_targets is not None and save and G is not None and self.head_loss_fusable():
+            if tuple(loss_targets.shape) != tuple(y.shape):
+                raise ValueError(f"loss targets {tuple(loss_targets.shape)} != head output {tuple(y.shape)}")
+            tg = loss_targets if (loss_targets.dtype == F32 and loss_targets.is_contiguous()) else loss_targets.to(F32).contiguous()
+            hl = h.shape[2]
+            nb = hp.head_loss_fused_ws_bytes(N, F_, hl, hl, g.head_k, g.head_p)
+            ws = self._zero_ws.get("head_fused")
+            if ws is None or ws.numel() * 4 != ((nb + 3) // 4) * 4 or ws.device != dev:
+                ws = self._zero_ws["head_fused"] = torch.zeros((nb + 3) // 4, dtype=F32, device=dev)   # ticket counter starts at zero
+            lpi = torch.empty(N, dtype=F32, device=dev)
+            lsum = torch.empty(1, dtype=F32, device=dev)
+            dout = torch.empty_like(h)
+            macs = N * F_ * g.head_k ** 2 * (2 * 5 * g.S ** 2 + 5 * hl * hl)          # forward + dW + dx
+            with self._t("head_loss_fused", N, hl, 2.0 * macs, self._act_bytes(N, hl, 2)):
+                hp.head_loss_fused(h, masks["head"] if masks is not None else None, P["out.weight"], P["out.bias"], tg, y, lpi, lsum,
+                                   dout, G["out.weight"], G["out.bias"], ws, g.head_k, g.head_p)
+            saved["loss"] = (lpi, lsum)
+            saved["head_dout"] = dout
+        else:
+            with self._t("head_fwd", N, h.shape[2], 2.0 * N * 5 * F_ * g.head_k ** 2 * g.S ** 2, self._act_bytes(N, h.shape[2], 1)):
+                hp.head_fwd(h, masks["head"] if masks is not None else None, P["out.weight"], P["out.bias"], y, g.head_k, g.head_p)
         if save:
             saved["h_last"] = h
             saved["y"] = y
@@ -388,15 +420,18 @@ class ConvStack:
         x, masks = saved["x"], saved["masks"]
         N, dev = x.shape[0], x.device
         h_last, y = saved["h_last"], saved["y"]
-        if tuple(dy.shape) != tuple(y.shape):
-            raise ValueError(f"dy shape {tuple(dy.shape)} != y shape {tuple(y.shape)}")
-        dy = dy.to(F32).contiguous()
-        hl = h_last.shape[2]
-        ws = self._workspace("head", hp.head_bwd_ws_bytes(N, F_, hl, hl, g.head_k, g.head_p), dev)
-        dout = torch.empty_like(h_last)
-        with self._t("head_bwd", N, hl, 4.0 * N * 5 * F_ * g.head_k ** 2 * g.S ** 2, self._act_bytes(N, hl, 2)):
-            hp.head_bwd(h_last, masks["head"] if masks is not None else None, P["out.weight"], y, dy, dout,
-                        G["out.weight"], G["out.bias"], ws, g.head_k, g.head_p)
+        if saved.get("head_dout") is not None:
+            dout = saved["head_dout"]                      # the fused head already ran its backward (G["out.*"] written)
+        else:
+            if dy is None or tuple(dy.shape) != tuple(y.shape):
+                raise ValueError(f"dy shape {None if dy is None else tuple(dy.shape)} != y shape {tuple(y.shape)}")
+            dy = dy.to(F32).contiguous()
+            hl = h_last.shape[2]
+            ws = self._workspace("head", hp.head_bwd_ws_bytes(N, F_, hl, hl, g.head_k, g.head_p), dev)
+            dout = torch.empty_like(h_last)
+            with self._t("head_bwd", N, hl, 4.0 * N * 5 * F_ * g.head_k ** 2 * g.S ** 2, self._act_bytes(N, hl, 2)):
+                hp.head_bwd(h_last, masks["head"] if masks is not None else None, P["out.weight"], y, dy, dout,
+                            G["out.weight"], G["out.bias"], ws, g.head_k, g.head_p)
         pending = []          # (x, dz, weight name) of same-resolution convs awaiting one batched wgrad launch
 
         side_keep = []        # tensors in use on the side stream: referenced until the streams are joined

@@ -679,6 +679,29 @@ def head_bwd(x, drop_scale, w, y, dy, dx, dW, db, ws, k, pad):
           "fdet_head_bwd")
 
 
+def head_loss_fused_supported(F_, H, W, k, pad) -> bool:
+    return bool(lib().fdet_head_loss_fused_supported(int(F_), int(H), int(W), int(k), int(pad)))
+
+
+def head_loss_fused_ws_bytes(Nn, F_, H, W, k, pad) -> int:
+    return int(lib().fdet_head_loss_fused_ws_bytes(Nn, F_, H, W, k, pad))
+
+
+def head_loss_fused(x, drop_scale, w, bias, gt, y, lpi, lsum, dx, dW, db, ws, k, pad):
+    """Training head + yolo_loss + their gradients in one launch sequence (fdet_head_loss_fused): fills y (N,5,S,S),
+    lpi (N,), lsum (1,), dx like x, dW (5,F,k,k), db (5,).  ws: zero-initialised workspace of head_loss_fused_ws_bytes()."""
+    Nn, F_, H, W = x.shape
+    _chk4(w, (5, F_, k, k), "w")
+    _chk4(dW, (5, F_, k, k), "dW")
+    _chk4(dx, x.shape, "dx")
+    _chk4(gt, y.shape, "gt")
+    if drop_scale is not None:
+        _chk4(drop_scale, (Nn, F_), "drop_scale")
+    check(lib().fdet_head_loss_fused(ptr(x), ptr(drop_scale), ptr(w), ptr(bias), ptr(gt), ptr(y), ptr(lpi), ptr(lsum), ptr(dx),
+                                     ptr(dW), ptr(db), ptr(ws, ws.dtype), ws.numel() * ws.element_size(), Nn, F_, H, W, k, pad,
+                                     stream()), "fdet_head_loss_fused")
+
+
 # ---- MobileNetV3 backbone (inference, bf16, NHWC activations) -------------------------------------------------------
 BF16 = torch.bfloat16
 MB_ACT = {"none": 0, "relu": 1, "hswish": 2}

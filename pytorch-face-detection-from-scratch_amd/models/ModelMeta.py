@@ -109,8 +109,12 @@ class ModelMeta(_Base):
                 P = {n: p.data for n, p in zip(names, params)}
         red = self._reducer
         masks = model._draw_masks(x.shape[0], x.device) if model.training else None
-        y_hat, saved = eng.forward(x, P, masks, save=True)
-        _, lsum, dy = hp.yolo_loss_fwd_bwd(y_hat, y, want_grad=True)
+        # PoolResnet geometry: head forward + yolo_loss + their gradients run as ONE fused kernel at the end of forward
+        y_hat, saved = eng.forward(x, P, masks, save=True, loss_targets=y if eng.head_loss_fusable() else None, G=G)
+        if saved.get("loss") is not None:
+            (_, lsum), dy = saved["loss"], None
+        else:
+            _, lsum, dy = hp.yolo_loss_fwd_bwd(y_hat, y, want_grad=True)
         eng.backward(saved, dy, P, G,
                      after_block=(lambda k: red.launch_tail() if k == self._split_block else None) if red.enabled else None)
         if red.enabled:

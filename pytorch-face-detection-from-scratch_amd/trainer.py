@@ -17,6 +17,7 @@ from typing import Callable, Iterable, List, Optional
 import torch
 
 from .datasets.feed import U8BatchFeeder
+from .hostinfo import limit_host_threads
 
 
 def _epoch(model_meta, batches, train: bool, feeder_cache: dict, on_step: Optional[Callable]):
@@ -75,6 +76,7 @@ def fit(model_meta, train_batches: Iterable, val_batches: Optional[Iterable] = N
         torchscript_path: Optional[str] = None, on_step: Optional[Callable] = None) -> dict:
     """Train `model_meta` (a ModelMeta) for `epochs` passes over `train_batches` (re-iterable), validating on
     `val_batches` after every epoch.  Returns {"train": [per-epoch metrics], "val": [...], "scripted": module or None}."""
+    limit_host_threads()                  # 256 OpenMP workers on a 16-core share stall the thread that feeds the GPU
     optimizers, schedulers = model_meta.configure_optimizers()
     sched = schedulers[0]
     feeder_cache: dict = {}

@@ -188,6 +188,69 @@ def test_head(hp, cfg):
     close(db, br.grad)
 
 
+@pytest.mark.parametrize("cfg", [(3, 15, True, False), (5, 15, False, False), (2, 12, True, True), (257, 15, True, False)])
+def test_head_loss_fused(hp, cfg):
+    """fdet_head_loss_fused (training head + yolo_loss + their gradients in one kernel, bf16x3 on the matrix cores) against
+    (1) the reference arithmetic on the CPU: Dropout2d scale -> Conv2d(64,5,6) -> sigmoid -> the oracle's yolo_loss per image,
+    summed (models/PoolResnet.py:100-102, losses/YoloLoss.py:4-44, models/ModelMeta.py:173-176) and torch autograd, and
+    (2) the separate launches it replaces (head_fwd, yolo_loss_fwd_bwd, head_bwd): the loss given y is bit-identical."""
+    import oracle as O
+    N, H, use_scale, with_nan_targets = cfg
+    Fi, k, p = 64, 6, 0
+    assert hp.head_loss_fused_supported(Fi, H, H, k, p)
+    assert not hp.head_loss_fused_supported(32, H, H, k, p) and not hp.head_loss_fused_supported(Fi, 20, 20, 3, 1)
+    S = H - k + 1
+    g = torch.Generator().manual_seed(7 * N + H)
+    x = torch.randn(N, Fi, H, H, generator=g)
+    w = torch.randn(5, Fi, k, k, generator=g) * 0.02
+    b = torch.randn(5, generator=g) * 0.1
+    scale = ((torch.rand(N, Fi, generator=g) > 0.5).float() / 0.5) if use_scale else None
+    boxes = O.synthetic_boxes(N, 48 * S, seed=3)
+    gt = torch.stack([O.encode_targets(bb, (48 * S, 48 * S), S) for bb in boxes])
+    # ---- CPU reference
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    xs = xr * scale[:, :, None, None] if use_scale else xr
+    y_ref = torch.sigmoid(F.conv2d(xs, wr, br))
+    l_ref = torch.stack([O.yolo_loss(y_ref[i], gt[i]) for i in range(N)])
+    l_ref.sum().backward()
+    # ---- fused
+    dev = "cuda"
+    xc, wc, bc, gc = x.to(dev), w.to(dev), b.to(dev), gt.to(dev)
+    sc = scale.to(dev) if use_scale else None
+    ws = torch.zeros((hp.head_loss_fused_ws_bytes(N, Fi, H, H, k, p) + 3) // 4, device=dev)
+    y = torch.full((N, 5, S, S), float("nan"), device=dev)
+    lpi = torch.full((N,), float("nan"), device=dev); lsum = torch.full((1,), float("nan"), device=dev)
+    dx = torch.full((N, Fi, H, H), float("nan"), device=dev)
+    dW = torch.full((5, Fi, k, k), float("nan"), device=dev); db = torch.full((5,), float("nan"), device=dev)
+    for _ in range(2):                                       # twice: the ticket counter in ws must come back to zero
+        lsum.fill_(float("nan"))
+        hp.head_loss_fused(xc, sc, wc, bc, gc, y, lpi, lsum, dx, dW, db, ws, k, p)
+        close(y, y_ref.detach(), 1e-5)
+        close(lpi, l_ref.detach(), 1e-4)
+        assert abs(float(lsum) - float(l_ref.sum())) <= 1e-4 * max(1.0, float(l_ref.sum()))
+        close(dx, xr.grad)
+        close(dW, wr.grad)
+        close(db, br.grad)
+    assert int(ws.view(torch.int32)[-16:].abs().sum()) == 0
+    # ---- the launches it replaces: same loss arithmetic on the same y -> identical bits
+    lpi2, lsum2, dy2 = hp.yolo_loss_fwd_bwd(y, gc, want_grad=True)
+    assert torch.equal(lpi2, lpi) and torch.equal(lsum2, lsum)
+    y3 = torch.empty_like(y)
+    hp.head_fwd(xc, sc, wc, bc, y3, k, p)
+    close(y, y3, 1e-5)
+    ws3 = torch.empty(hp.head_bwd_ws_bytes(N, Fi, H, H, k, p) // 4, device=dev)
+    dx3 = torch.empty_like(dx); dW3 = torch.empty_like(dW); db3 = torch.empty_like(db)
+    hp.head_bwd(xc, sc, wc, y, dy2, dx3, dW3, db3, ws3, k, p)
+    close(dx, dx3); close(dW, dW3); close(db, db3)
+    if with_nan_targets:
+        # a NaN prediction cannot come out of a sigmoid of finite sums; the NaN / inf handling of yolo_loss (Q6) is covered
+        # through identical instructions in k_yolo_loss (test_gpu_detect.py); here: an all-zero target image (no object)
+        gz = gc.clone(); gz[0] = 0.0
+        hp.head_loss_fused(xc, sc, wc, bc, gz, y, lpi, lsum, dx, dW, db, ws, k, p)
+        lz = O.yolo_loss(y_ref[0].detach(), gt[0] * 0.0)
+        assert abs(float(lpi[0]) - float(lz)) <= 1e-4 * max(1.0, float(lz))
+
+
 @pytest.mark.parametrize("cfg", [(3, 15, 15, 3, True), (2, 10, 10, 2, False), (5, 15, 15, 8, True), (1, 7, 9, 1, True)])
 def test_block_chain_fwd_bwd(hp, cfg):
     """LDS-resident residual-block chain (fdet_block_chain_{fwd,bwd}_bf16x3) against torch CPU fp32:

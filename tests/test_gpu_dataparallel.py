@@ -59,14 +59,26 @@ def test_two_ranks_fused_train_step_equals_single_process(tmp_path, live_dropout
     # flipped on a ~0 gradient (below)
     assert float((g_got - g_ref).abs().max()) <= 1e-4 * gmax
     lr = 1e-4
+    off = 0
     for k, p_ref in params.items():
         p_got = got["params"][k]
+        n = p_ref.numel()
+        g1, g2 = g1_ref[off:off + n].view_as(p_ref), g_ref[off:off + n].view_as(p_ref)   # flat order = state_dict order
+        off += n
         d = (p_got - p_ref).abs()
-        # Adam's first updates are ~lr*sign(g): where the gradient is far from zero the parameters agree to fp32
-        # rounding (1e-6 relative); an entry whose gradient is ~0 may flip the sign of its update
+        # Adam's first updates are ~lr*sign(g): an entry whose gradient is ~0 may flip the sign of its update (at most
+        # 2 lr per step apart) ...
         assert float(d.max()) <= 2.1 * lr * steps, k
-        frac_tight = float((d <= 1e-6 * max(1.0, float(p_ref.abs().max()))).float().mean())
-        assert frac_tight >= 0.999, (k, frac_tight)
+        tight = d <= 1e-6 * max(1.0, float(p_ref.abs().max()))
+        # ... and EVERY entry whose gradient is clear of zero in both steps agrees to fp32 rounding (1e-6 relative,
+        # SURVEY.md 8e); how many entries sit near zero is a property of the batch, not of the arithmetic
+        # (step 2 moves a parameter along m2 ~ 0.9 g1 + g2: that combination must be clear of zero as well)
+        m2 = 0.9 * g1 + g2
+        clear = (g1.abs() > 1e-3 * float(g1.abs().max())) & (g2.abs() > 1e-3 * float(g2.abs().max())) & \
+                (m2.abs() > 1e-2 * float(m2.abs().max()))
+        assert int(clear.sum()) >= 0.1 * n or n < 64, (k, int(clear.sum()), n)      # the check is not vacuous
+        assert bool(tight[clear].all()), (k, int((~tight[clear]).sum()), int(clear.sum()))
+        assert float(tight.float().mean()) >= 0.99, (k, float(tight.float().mean()))
 
 
 @pytest.mark.timeout(900)

@@ -691,17 +691,26 @@ def test_full_batch_pre_split_path_equals_fp32_io_path(fd, monkeypatch):
         mm = ModelMeta(model=model, lr=1e-4)
         mm.configure_optimizers()
         model.train()
-        y3 = None
+        y3 = y3i = None
         if ps_on == "1":                                     # (before the step: Adam changes the parameters)
             model.set_dropout_masks({k: v[:3] for k, v in masks.items()})
             with torch.no_grad():
-                y3 = model(x[:3].contiguous()).clone()
+                y3i = model(x[:3].contiguous()).clone()      # inference-style forward: the fp32 VALU head (fdet_head_fwd)
+            twin = _load(_build(fd, "poolresnet", F, size, S, nb), P).train()
+            twin.set_dropout_masks({k: v[:3] for k, v in masks.items()})
+            mm3 = ModelMeta(model=twin, lr=1e-4)
+            mm3.configure_optimizers()
+            _, y3, _ = mm3.fused_train_step(x[:3].contiguous(), y[:3].contiguous())   # the same path as the full batch
+            y3 = y3.clone()
+            del twin, mm3
         model.set_dropout_masks(masks)
         lsum, y_hat, _ = mm.fused_train_step(x, y)
         names, params = model.named_stack_params()
         out[ps_on] = (float(lsum), y_hat.clone(), mm.opt.space.grad.clone(), names, [p.shape for p in params])
         if y3 is not None:
-            assert torch.equal(y3, y_hat[:3])
+            assert torch.equal(y3, y_hat[:3])                # bit for bit: the result does not depend on the batch
+            # the training step's head is the fused bf16x3 kernel (fdet_head_loss_fused), the plain forward's the fp32 one
+            assert float((y3i - y_hat[:3]).abs().max()) <= 1e-5
     (la, ya, ga, names, shapes), (lb, yb, gb, _, _) = out["1"], out["0"]
     assert abs(la - lb) <= 1e-6 * abs(lb), (la, lb)
     assert float((ya - yb).abs().max()) <= 1e-5
