@@ -16,7 +16,7 @@
 //   * the loss and its gradient are computed by wave 0 with the instruction sequence of k_yolo_loss (fdet_detect.hip) on
 //     the sigmoid outputs in LDS: loss_per_image and loss_sum are bit-identical to the unfused path; the last workgroup
 //     to finish adds the per-image losses in k_sum_fixed's order (ticket counter in the workspace, reset by its user);
-//   * per-image slabs [tap][8][64] + fixed-order reduce (k_head_fused_reduce): deterministic, batch-size independent.
+//   * per-image slabs [tap][5][64] + fixed-order reduce (k_head_fused_reduce): deterministic, batch-size independent.
 #include "fdet_common.h"
 #include <cfloat>
 
@@ -58,7 +58,7 @@ struct HeadFusedArgs {
   float* lsum;               // [1] batch sum (or null)
   unsigned* counter;         // ticket counter (zero between launches)
   float* dx;                 // [N,64,H,W]
-  float* wsW;                // [N][36][8][64] weight-gradient slabs
+  float* wsW;                // [N][36][5][64] weight-gradient slabs
   float* wsb;                // [N][8] bias-gradient slabs
   int N, H, W, So, Wo;
 };
@@ -97,28 +97,47 @@ k_head_fused(const HeadFusedArgs a) {
   const int n = blockIdx.x;
   const int H = a.H, W = a.W, HW = H * W, So = a.So, Wo = a.Wo, P = So * Wo;
 
-  // ---- zero fill (pads of every operand image) and the image's dropout scales
+  // ---- stage: item = (channel group, position): 8 channels of one position -> one unit per plane (Xb) + 8 scalars (XT).
+  // A thread owns up to 4 items (8 * 225 / 512); all of its 32 global loads are issued before the first is used.
   {
-    hf_f32x4* z = reinterpret_cast<hf_f32x4*>(smem);
-    for (int t = tid; t < HF_OFF_PART / 16; t += HF_T) z[t] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < HF_F) sc[tid] = a.scale ? a.scale[(size_t)n * HF_F + tid] : 1.f;
-  }
-  __syncthreads();
-  // ---- stage: item = (channel group, position): 8 channels of one position -> one unit per plane (Xb) + 8 scalars (XT)
-  for (int t = tid; t < 8 * HW; t += HF_T) {
-    const int cg = t / HW, p = t - cg * HW;
-    const int iy = p / W, ix = p - iy * W, q = iy * 16 + ix;
-    float v[8];
+    constexpr int IT = 4;
+    float v[IT][8];
+    int qi[IT], cgi[IT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = a.x[((size_t)n * HF_F + 8 * cg + j) * HW + p] * sc[8 * cg + j];
-    hf_bf16x8 hi, lo;
-    hf_split8(v, hi, lo);
-    Xb[(0 * 8 + cg) * HF_XPT + q] = hi;
-    Xb[(1 * 8 + cg) * HF_XPT + q] = lo;
+    for (int r = 0; r < IT; ++r) {
+      const int t = tid + r * HF_T;
+      const bool ok = t < 8 * HW;
+      const int tc = ok ? t : 0;
+      const int cg = tc / HW, p = tc - cg * HW;
+      const int iy = p / W, ix = p - iy * W;
+      cgi[r] = cg; qi[r] = ok ? iy * 16 + ix : -1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      XT[(0 * HF_F + 8 * cg + j) * HF_XTP + q] = hi[j];
-      XT[(1 * HF_F + 8 * cg + j) * HF_XTP + q] = lo[j];
+      for (int j = 0; j < 8; ++j) v[r][j] = a.x[((size_t)n * HF_F + 8 * cg + j) * HW + p];
+    }
+    // zero fill (pads of every operand image) and the image's dropout scales, under the latency of those loads
+    {
+      hf_f32x4* z = reinterpret_cast<hf_f32x4*>(smem);
+      for (int t = tid; t < HF_OFF_PART / 16; t += HF_T) z[t] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tid < HF_F) sc[tid] = a.scale ? a.scale[(size_t)n * HF_F + tid] : 1.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < IT; ++r) {
+      if (qi[r] >= 0) {
+        const int cg = cgi[r], q = qi[r];
+        float w8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w8[j] = v[r][j] * sc[8 * cg + j];
+        hf_bf16x8 hi, lo;
+        hf_split8(w8, hi, lo);
+        Xb[(0 * 8 + cg) * HF_XPT + q] = hi;
+        Xb[(1 * 8 + cg) * HF_XPT + q] = lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          XT[(0 * HF_F + 8 * cg + j) * HF_XTP + q] = hi[j];
+          XT[(1 * HF_F + 8 * cg + j) * HF_XTP + q] = lo[j];
+        }
+      }
     }
   }
   __syncthreads();
@@ -131,12 +150,23 @@ k_head_fused(const HeadFusedArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc[i] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
     const int orow = m < 7 ? m : 7;                        // rows 5..15 read a zero slot of the pack
-    for (int tap = 18 * kh; tap < 18 * kh + 18; ++tap) {
+    // the A fragments come from L2 (74 KB pack, the same for every workgroup): a ring of three taps, loaded two taps ahead
+    hf_bf16x8 ra[3][2][2];                                 // [ring][c32][plane]
+#define HF_LOAD_WF(R, TAP)                                                                        \
+    _Pragma("unroll") for (int c32_ = 0; c32_ < 2; ++c32_)                                         \
+      _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                          \
+        ra[R][c32_][pl_] = a.wf[(((pl_ * HF_KK + (TAP)) * 2 + c32_) * 4 + kg) * 8 + orow];
+    const int tap0 = 18 * kh;
+    HF_LOAD_WF(0, tap0)
+    HF_LOAD_WF(1, tap0 + 1)
+#pragma unroll
+    for (int tt = 0; tt < 18; ++tt) {
+      const int tap = tap0 + tt;
+      if (tt + 2 < 18) { HF_LOAD_WF((tt + 2) % 3, tap + 2) }
       const int ky = tap / HF_K, kx = tap - ky * HF_K, toff = ky * 16 + kx;
 #pragma unroll
       for (int c32 = 0; c32 < 2; ++c32) {
-        const hf_bf16x8 ah = a.wf[(((0 * HF_KK + tap) * 2 + c32) * 4 + kg) * 8 + orow];
-        const hf_bf16x8 al = a.wf[(((1 * HF_KK + tap) * 2 + c32) * 4 + kg) * 8 + orow];
+        const hf_bf16x8 ah = ra[tt % 3][c32][0], al = ra[tt % 3][c32][1];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           if (i < nt) {
@@ -148,6 +178,7 @@ k_head_fused(const HeadFusedArgs a) {
         }
       }
     }
+#undef HF_LOAD_WF
     // C: column = lane & 15 (position), row = 4 * (lane >> 4) + register (output channel)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -269,12 +300,18 @@ k_head_fused(const HeadFusedArgs a) {
     hf_f32x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 3
+    hf_bf16x8 rd[3][2];                                    // [ring][plane]: A fragments two K steps ahead (L2)
+#define HF_LOAD_WD(R, KS)                                                                         \
+    _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                            \
+      rd[R][pl_] = a.wd[(pl_ * HF_KK + 4 * (KS) + kg) * HF_F + 16 * mt + m];
+    HF_LOAD_WD(0, 0)
+    HF_LOAD_WD(1, 1)
+#pragma unroll
     for (int ks = 0; ks < HF_KK / 4; ++ks) {
+      if (ks + 2 < HF_KK / 4) { HF_LOAD_WD((ks + 2) % 3, ks + 2) }
       const int tap = 4 * ks + kg;
       const int ky = tap / HF_K, kx = tap - ky * HF_K, toff = ky * 16 + kx;
-      const hf_bf16x8 ah = a.wd[(0 * HF_KK + tap) * HF_F + 16 * mt + m];
-      const hf_bf16x8 al = a.wd[(1 * HF_KK + tap) * HF_F + 16 * mt + m];
+      const hf_bf16x8 ah = rd[ks % 3][0], al = rd[ks % 3][1];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (i < nr) {
@@ -285,6 +322,7 @@ k_head_fused(const HeadFusedArgs a) {
         }
       }
     }
+#undef HF_LOAD_WD
     // C: column = position ix = lane & 15, row = channel 16 mt + 4 kg + register
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -303,7 +341,7 @@ k_head_fused(const HeadFusedArgs a) {
   {
     const int nt = wid & 3, kx0 = (wid >> 2) * 3;
     const int orow = m < 4 ? m : 4;
-    float* const slab = a.wsW + (size_t)n * HF_KK * 8 * HF_F;
+    float* const slab = a.wsW + (size_t)n * HF_KK * 5 * HF_F;
     for (int kx = kx0; kx < kx0 + 3; ++kx) {
       hf_bf16x8 ah[5], al[5];
 #pragma unroll
@@ -328,7 +366,7 @@ k_head_fused(const HeadFusedArgs a) {
       // C: column = channel 16 nt + (lane & 15), row = o = 4 kg + register
 #pragma unroll
       for (int ky = 0; ky < HF_K; ++ky) {
-        float* const s = slab + (size_t)((ky * HF_K + kx) * 8) * HF_F + 16 * nt + m;
+        float* const s = slab + (size_t)((ky * HF_K + kx) * 5) * HF_F + 16 * nt + m;
         if (kg == 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[r * HF_F] = acc[ky][r];
@@ -394,12 +432,11 @@ k_head_fused_reduce(const float* __restrict__ wsW, const float* __restrict__ wsb
                     float* __restrict__ db) {
   __shared__ float part[1024];
   const int q = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int nS = HF_KK * 8 * HF_F;
-  const int t = blockIdx.x * 64 + q;                       // slab entry (tap, o-slot, c), or nS + o for the bias
+  const int nS = HF_KK * 5 * HF_F;
+  const int t = blockIdx.x * 64 + q;                       // slab entry (tap, o, c), or nS + o for the bias
   float s = 0.f;
   if (t < nS) {
-    if (((t >> 6) & 7) < 5)
-      for (int n = ph; n < N; n += 16) s += wsW[(size_t)n * nS + t];
+    for (int n = ph; n < N; n += 16) s += wsW[(size_t)n * nS + t];
   } else if (t < nS + 5) {
     for (int n = ph; n < N; n += 16) s += wsb[(size_t)n * 8 + (t - nS)];
   }
@@ -410,8 +447,8 @@ k_head_fused_reduce(const float* __restrict__ wsW, const float* __restrict__ wsb
 #pragma unroll
     for (int p = 0; p < 16; ++p) tot += part[p * 64 + q];
     if (t < nS) {
-      const int c = t & 63, o = (t >> 6) & 7, tap = t >> 9;
-      if (o < 5) dW[((size_t)o * HF_F + c) * HF_KK + tap] = tot;
+      const int c = t & 63, r = t >> 6, o = r % 5, tap = r / 5;
+      dW[((size_t)o * HF_F + c) * HF_KK + tap] = tot;
     } else if (t < nS + 5) {
       db[t - nS] = tot;
     }
@@ -429,7 +466,7 @@ extern "C" int fdet_head_loss_fused_supported(int F, int H, int W, int k, int pa
 
 extern "C" size_t fdet_head_loss_fused_ws_bytes(int N, int F, int H, int W, int k, int pad) {
   if (!fdet_head_loss_fused_supported(F, H, W, k, pad) || N < 1) return 0;
-  return hf_pack_units() * 16 + ((size_t)N * HF_KK * 8 * HF_F + (size_t)N * 8) * 4 + 64;
+  return hf_pack_units() * 16 + ((size_t)N * HF_KK * 5 * HF_F + (size_t)N * 8) * 4 + 64;
 }
 
 // One launch sequence (pack, fused kernel, slab reduce) for
@@ -453,7 +490,7 @@ extern "C" int fdet_head_loss_fused(const float* x, const float* drop_scale, con
   hf_bf16x8* wf = pk;
   hf_bf16x8* wd = pk + (size_t)2 * HF_KK * 2 * 4 * 8;
   float* wsW = reinterpret_cast<float*>(pk + hf_pack_units());
-  float* wsb = wsW + (size_t)N * HF_KK * 8 * HF_F;
+  float* wsb = wsW + (size_t)N * HF_KK * 5 * HF_F;
   unsigned* counter = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + need - 64);
   a.x = x; a.scale = drop_scale; a.wf = wf; a.wd = wd; a.bias = bias; a.gt = gt; a.y = y; a.lpi = loss_per_image;
   a.lsum = loss_sum; a.counter = counter; a.dx = dx; a.wsW = wsW; a.wsb = wsb;
@@ -467,7 +504,7 @@ extern "C" int fdet_head_loss_fused(const float* x, const float* drop_scale, con
   }
   hipLaunchKernelGGL(k_head_fused, dim3(N), dim3(HF_T), HF_LDS, st, a);
   if (int rc = check_launch("fdet_head_loss_fused")) return rc;
-  const int nS = HF_KK * 8 * HF_F;
+  const int nS = HF_KK * 5 * HF_F;
   hipLaunchKernelGGL(k_head_fused_reduce, dim3((nS + 5 + 63) / 64), dim3(1024), 0, st, wsW, wsb, N, dW, db);
   return check_launch("fdet_head_loss_fused(reduce)");
 }
