@@ -301,6 +301,45 @@ def infer_bench(model, size, device, frames=100, warm=20):
                     "random-init weights); demo path = 2 stacked frames per call, boxes of image 0 read by the host"}
 
 
+def precision16_leg(B, size, S, F_, device, steps, warm):
+    """SECOND key, never the headline: the same training step in `precision16` (engine.set_precision("bf16")): bf16
+    activations and weights, ONE MFMA pass, fp32 accumulation / epilogues / master weights / optimizer -- the arithmetic of
+    the reference's own Trainer(precision=16) (train_model.py:50).  This is the only regime in which the north star's
+    "fraction of the HBM roofline" is defined for this model: 13.45 MB per image of 16-bit activation
+    traffic against 0.31 ms of MFMA work.  Pinned by tests/test_gpu_p16.py against the reference run under
+    torch.autocast("cpu", bfloat16) (fixture g17)."""
+    from fdet_amd.models import ModelMeta
+    from fdet_amd.models.PoolResnet import PoolResnet
+    from fdet_amd.convstack import KernelTimer
+    torch.manual_seed(0)
+    model = PoolResnet(filters=F_, input_shape=(3, size, size), num_of_patches=S, num_of_residual_blocks=10).to(device).train()
+    model.engine.set_precision("bf16")
+    mm = ModelMeta(model=model, lr=1e-4)
+    mm.configure_optimizers()
+    x, y, _ = synth_batch(B, size, S, seed=100, device=device)
+    dt, r = _time_steps(lambda: mm.fused_train_step(x, y), warm, steps)
+    timer = KernelTimer()
+    model.engine.timer = timer
+    for _ in range(3):
+        mm.fused_train_step(x, y)
+    model.engine.timer = None
+    per = timer.summary()
+    ms = dt * 1e3
+    gb16 = 0.5 * STEP_MB_PER_IMAGE_F64 * B / 1e3            # SURVEY.md 8d: 13.45 MB per image in 16-bit activations
+    gf = STEP_GFLOP_PER_IMAGE_F64 * B
+    t_hbm, t_mfma = gb16 / PEAK_HBM_GBS * 1e3, gf / (PEAK_BF16_MFMA_TFLOPS * 1e3) * 1e3
+    kern = {k: round(tot / 3, 4) for k, (n_l, tot, fl, nb) in sorted(per.items(), key=lambda kv: -kv[1][1])}
+    return {"ms_per_step": round(ms, 3), "imgs_per_s": round(B / dt, 1), "dtype": "bf16 (one MFMA pass, fp32 accumulate, fp32 master weights)",
+            "finite_loss": bool(torch.isfinite(r[0]).all()), "final_loss": round(float(r[0]), 4),
+            "step_roofline": {"algorithmic_gb_per_step_16bit": round(gb16, 3), "hbm_floor_ms": round(t_hbm, 3),
+                              "mfma_floor_ms": round(t_mfma, 3), "hbm_frac": round(gb16 / (ms * 1e-3) / PEAK_HBM_GBS, 4),
+                              "frac_of_max_floor": round(max(t_hbm, t_mfma) / ms, 4),
+                              "note": "the stem still reads the fp32 input (2.76 MB per image and pass) and the pooled-gradient "
+                                      "routing still writes both planes: traffic above the 16-bit figure"},
+            "kernels_ms_per_step": kern,
+            "what": "same model, batch and step as the headline with engine.set_precision('bf16'); a second key, not `value`"}
+
+
 def _time_steps(fn, warm, steps):
     for _ in range(warm):
         fn()
@@ -447,6 +486,7 @@ def main():
     ap.add_argument("--no-inference", action="store_true", help="skip the inference leg (profiling runs: its launches share kernel symbols with training)")
     ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / 4 / 5 legs")
     ap.add_argument("--no-feed", action="store_true", help="skip the metrics-on / PCIe-inclusive / trainer.fit legs")
+    ap.add_argument("--no-p16", action="store_true", help="skip the precision16 leg (second key)")
     ap.add_argument("--concat-ranks", type=int, default=0,
                     help="(tests) one process whose batch is the concatenation of the shards R ranks would draw")
     args = ap.parse_args()
@@ -615,6 +655,12 @@ def main():
         if world == 1 and not args.no_feed:
             out.update(feed_legs(mm, model, B, size, S, device, steps=min(args.steps, 10)))
         _log(f"headline timed: {ms:.3f} ms/step")
+        if world == 1 and not args.no_p16 and F_ == 64:
+            _log("precision16 leg")
+            try:
+                out["precision16"] = precision16_leg(B, size, S, F_, device, steps=args.steps, warm=args.warmup)
+            except Exception as e:                           # noqa: BLE001 (a leg must not take the headline line down)
+                out["precision16"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_inference:
             _log("inference leg")
             out["inference"] = infer_bench(model, size, device)

@@ -444,6 +444,33 @@ int fdet_head_bwd(const float* x, const float* drop_scale, const float* w, const
                   const float* dy, float* dx, float* dW, float* db, void* ws, size_t ws_bytes,
                   int N, int F, int H, int W, int k, int pad, void* stream);
 
+/* precision16 (round 4): the PS kernels with ONE bf16 MFMA pass on the hi planes -- bf16 activations and weights, fp32
+ * accumulation, fp32 epilogue arithmetic and fp32 master weights / gradients: the arithmetic of the reference's
+ * Trainer(precision=16) (train_model.py:50) with bf16 as the 16-bit type.  Same arguments as the functions without the
+ * suffix; the PS tensors they produce hold their hi plane only (the lo plane is left untouched: zero in a buffer that only
+ * ever served this mode). */
+int fdet_conv3x3_ps_fwd_p16(const void* x_ps, const void* wpk, const float* bias, void* y_ps, int N, int Cin,
+                            int Cout, int H, int W, float slope, void* stream);
+int fdet_conv3x3_ps_dgrad_act_p16(const void* dz_ps, const void* wpk, const void* act_ps, void* dx_ps, int N,
+                                  int Cin, int Cout, int H, int W, float slope, void* stream);
+int fdet_conv3x3_ps_fwd_pool_p16(const void* x_ps, const void* wpk, const float* bias, const void* skip_ps,
+                                 const float* drop_scale, void* pool_ps, float* pool_f32, unsigned char* route8,
+                                 int N, int Cin, int Cout, int H, int W, float slope, void* stream);
+int fdet_conv3x3_ps_dgrad_unpool_p16(const void* dz_ps, const void* wpk, const float* dout_pooled,
+                                     const unsigned char* route8, float* dx, int N, int Cin, int Cout, int H, int W,
+                                     float slope, void* stream);
+int fdet_conv3x3_wgrad_ps_batched_p16(const void* const* h_x, const void* const* h_dz, float* const* h_dW,
+                                      float* const* h_db, int L, int N, int C, int H, int W, void* ws,
+                                      size_t ws_bytes, void* stream);
+int fdet_block_chain_fwd_ps_p16(const void* x, int x_is_ps, const void* const* h_wpk1, const float* const* h_b1,
+                                const void* const* h_wpk2, const float* const* h_b2, const float* const* h_scale,
+                                void* const* h_a_ps, void* const* h_c_ps, void* const* h_out_ps, float* out_last,
+                                int nblocks, int N, int F, int H, int W, float slope, void* stream);
+int fdet_block_chain_bwd_ps_p16(const float* dout, const void* const* h_wpk1b, const void* const* h_wpk2b,
+                                const float* const* h_scale, const void* const* h_a_ps, const void* const* h_c_ps,
+                                void* const* h_dz1_ps, void* const* h_dz2_ps, float* dx, int nblocks, int N, int F,
+                                int H, int W, float slope, void* stream);
+
 /* Training head fused with the loss (round 4): ONE launch sequence for what models/PoolResnet.py:100-102 +
  * losses/YoloLoss.py:4-44 (called per image and summed, models/ModelMeta.py:173-176) + their autograd compute:
  *   y = sigmoid(conv(x * drop_scale, w) + bias);  loss_per_image[n] = yolo_loss(y[n], gt[n]);  loss_sum = sum_n;

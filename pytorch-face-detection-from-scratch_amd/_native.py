@@ -119,6 +119,13 @@ SIGNATURES = {
     "fdet_head_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_head_bwd_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "fdet_head_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _P]),
+    "fdet_conv3x3_ps_fwd_p16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_ps_dgrad_act_p16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_ps_fwd_pool_p16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_ps_dgrad_unpool_p16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_conv3x3_wgrad_ps_batched_p16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "fdet_block_chain_fwd_ps_p16": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "fdet_block_chain_bwd_ps_p16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_head_loss_fused_supported": (_I, [_I, _I, _I, _I, _I]),
     "fdet_head_loss_fused_ws_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "fdet_head_loss_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _P]),

@@ -144,7 +144,7 @@ class ConvStack:
         # FDET_PRECISION=f32 forces the exact path.
         import os
         want = os.environ.get("FDET_PRECISION", "bf16x3")
-        self.x3 = (want == "bf16x3") and hp.x3_supported(geo.filters, geo.filters)
+        self.x3 = (want in ("bf16x3", "bf16")) and hp.x3_supported(geo.filters, geo.filters)
         # pooled blocks: dropout*skip*maxpool (and its backward) inside the conv epilogues (FDET_POOL_FUSION=0: the
         # separate elementwise tail kernels of round 1)
         self.pool_fusion = self.x3 and os.environ.get("FDET_POOL_FUSION", "1") != "0"
@@ -160,10 +160,25 @@ class ConvStack:
         # and their gradients live as bf16 hi|lo units, staged by LDS-DMA (FDET_PS=0: the fp32-I/O kernels of round 2)
         self.ps = self.pool_fusion and geo.filters == 64 and os.environ.get("FDET_PS", "1") != "0"
         self._ps_pool: Dict[tuple, list] = {}
+        # precision16 (FDET_PRECISION=bf16 or set_precision("bf16")): the PS kernels run ONE bf16 MFMA pass on the hi planes
+        # (bf16 activations and weights, fp32 accumulation / epilogues / master weights) -- the arithmetic of the reference's
+        # Trainer(precision=16), train_model.py:50, with bf16 as the 16-bit type.  Only where the PS path runs (64 channels);
+        # the stem, the head and the pooled-gradient routing keep their fp32-grade kernels.
+        self.p16 = self.ps and want == "bf16"
+        self._cur_N = 1                                    # batch size of the pass being planned (forward() sets it)
         # training head fused with the loss (fdet_head_loss_fused: forward + yolo_loss + their gradients in one kernel on
         # the matrix cores); FDET_HEAD_FUSED=0 keeps the separate head_fwd / yolo_loss / head_bwd launches
         self.head_fused = self.x3 and os.environ.get("FDET_HEAD_FUSED", "1") != "0"
         self._zero_ws: Dict[str, torch.Tensor] = {}
+
+    def set_precision(self, name: str) -> None:
+        """"bf16x3" (fp32-grade, default) or "bf16" (precision16: one MFMA pass; needs the PS path)."""
+        if name not in ("bf16x3", "bf16"):
+            raise ValueError("precision must be 'bf16x3' or 'bf16'")
+        if name == "bf16" and not self.ps:
+            raise ValueError("precision16 needs the pre-split path (64 channels, bf16x3-capable geometry)")
+        self.p16 = name == "bf16"
+        self._ps_pool.clear()                              # a bf16x3 pass may have left lo planes in pooled buffers
 
     def head_loss_fusable(self) -> bool:
         """The fused training head (forward + loss + backward of the head in one launch) covers this geometry."""
@@ -227,7 +242,9 @@ class ConvStack:
         if not self.ps or k >= len(self.lv):
             return False
         hk, pool = self.lv[k]
-        return pool == 2 and hk % 2 == 0 and 30 <= hk <= 62 and self._fused_pool(hk)
+        # (the batch-dependent limits of run_ps: 32-bit byte offsets of the fp32 tensors the pooled modes touch)
+        return pool == 2 and hk % 2 == 0 and 30 <= hk <= 62 and self._fused_pool(hk, self._cur_N) and \
+            self._cur_N * self.geo.filters * hk * hk * 4 < 2 ** 31
 
     def _ps_chain(self, k: int) -> bool:
         """The chain run starting at block k keeps its per-block tensors in PS (fdet_block_chain_*_ps) and its weight
@@ -235,7 +252,8 @@ class ConvStack:
         if not self.ps or k >= len(self.lv) or self._chain_run(k) <= 1:
             return False
         hk = self.lv[k][0]
-        return psm.conv3x3_wgrad_ps_ws_bytes(1, 1, self.geo.filters, hk, hk) > 0
+        return psm.conv3x3_wgrad_ps_ws_bytes(1, self._cur_N, self.geo.filters, hk, hk) > 0 and \
+            self._cur_N * self.geo.filters * hk * hk * 4 < 2 ** 31
 
     def _ps_take(self, scope: "_PsScope", N: int, C: int, H: int, W: int, dev) -> "psm.PsTensor":
         """A zero-haloed PS buffer from the engine's pool; it returns to the pool when `scope` (kept alive by the saved
@@ -277,6 +295,11 @@ class ConvStack:
             x = x.to(F32).contiguous()
         self._ensure_packed(P)
         N, F_, dev = x.shape[0], g.filters, x.device
+        if N != self._cur_N:
+            # PS buffers are sized per batch: a pool filled for another N (a last partial batch, a validation batch) would
+            # only pile up ~260 MB sets outside the caching allocator -- drop it
+            self._ps_pool.clear()
+            self._cur_N = N
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
         h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev) if not (self._ps_block(0) and self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)) else None
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
@@ -304,14 +327,14 @@ class ConvStack:
                     h_ps = psm.PsTensor.from_f32(h, out=self._ps_take(scope, N, F_, hk, hk, dev))
                 a_ps = self._ps_take(scope, N, F_, hk, hk, dev)
                 with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2)):
-                    psm.conv3x3_ps_fwd(h_ps, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], a_ps, self.slope)
+                    psm.conv3x3_ps_fwd(h_ps, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], a_ps, self.slope, p16=self.p16)
                 nxt = self._ps_block(k + 1) or self._ps_chain(k + 1)
                 out_ps = self._ps_take(scope, N, F_, hk // 2, hk // 2, dev) if nxt else None
                 out = None if nxt else torch.empty(N, F_, hk // 2, hk // 2, dtype=F32, device=dev)
                 route = psm.route8_like(N, F_, hk, hk, dev) if save else None
                 with self._t("conv3x3_fwd_pool", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2 + 0.25 + (1 / 16 if save else 0))):
                     psm.conv3x3_ps_fwd_pool(a_ps, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], h_ps, sc, out_ps, out,
-                                            route, self.slope)
+                                            route, self.slope, p16=self.p16)
                 if save:
                     saved["blocks"].append((h_ps, a_ps, route))
                 h, h_ps = out, out_ps
@@ -330,7 +353,8 @@ class ConvStack:
                 with self._t("chain_fwd", N, hk, 2 * run * self._conv_flops(N, hk), self._act_bytes(N, hk, 1 + (2.5 * run if save else 1))):
                     psm.block_chain_fwd_ps(h_ps, [self._wpk[nm + ".conv1.f"] for nm in names], [P[nm + ".conv1.bias"] for nm in names],
                                            [self._wpk[nm + ".conv2.f"] for nm in names], [P[nm + ".conv2.bias"] for nm in names],
-                                           [masks[nm] for nm in names] if masks is not None else None, a_l, c_l, o_l, out, self.slope)
+                                           [masks[nm] for nm in names] if masks is not None else None, a_l, c_l, o_l, out, self.slope,
+                                           p16=self.p16)
                 if save:
                     for i in range(run):
                         saved["blocks"].append((h_ps if i == 0 else o_l[i - 1], a_l[i], c_l[i]))
@@ -419,6 +443,7 @@ class ConvStack:
         F_ = g.filters
         x, masks = saved["x"], saved["masks"]
         N, dev = x.shape[0], x.device
+        self._cur_N = N                                    # the path decisions below are those of this pass's forward
         h_last, y = saved["h_last"], saved["y"]
         if saved.get("head_dout") is not None:
             dout = saved["head_dout"]                      # the fused head already ran its backward (G["out.*"] written)
@@ -476,7 +501,8 @@ class ConvStack:
                 wsb_ = self._workspace("wgrad_ps", psm.conv3x3_wgrad_ps_ws_bytes(len(grp), N, F_, hk_, hk_), dev)
                 with self._t("conv3x3_wgrad", N, hk_, fl_ * len(grp), self._act_bytes(N, hk_, 2) * len(grp)):
                     psm.conv3x3_wgrad_ps_batched([p_[0] for p_ in grp], [p_[1] for p_ in grp],
-                                                 [G[p_[2] + ".weight"] for p_ in grp], [G[p_[2] + ".bias"] for p_ in grp], wsb_)
+                                                 [G[p_[2] + ".weight"] for p_ in grp], [G[p_[2] + ".bias"] for p_ in grp], wsb_,
+                                                 p16=self.p16)
             pending_ps.clear()
 
         # runs of blocks that went through the forward chain come back through the backward chain
@@ -513,7 +539,8 @@ class ConvStack:
                 dx = torch.empty_like(dout)
                 with self._t("chain_bwd", N, hk, 2 * len(ks) * self._conv_flops(N, hk), self._act_bytes(N, hk, 2 + 3 * len(ks))):
                     psm.block_chain_bwd_ps(dout, [self._wpk[nm + ".conv1.b"] for nm in names], [self._wpk[nm + ".conv2.b"] for nm in names],
-                                           [masks[nm] for nm in names] if masks is not None else None, a_l, c_l, dz1_l, dz2_l, dx, self.slope)
+                                           [masks[nm] for nm in names] if masks is not None else None, a_l, c_l, dz1_l, dz2_l, dx, self.slope,
+                                           p16=self.p16)
                 for i in reversed(range(len(ks))):
                     pending_ps.append((a_l[i], dz2_l[i], names[i] + ".conv2"))
                     pending_ps.append((x_l[i], dz1_l[i], names[i] + ".conv1"))
@@ -573,10 +600,10 @@ class ConvStack:
                     psm.pool_route_bwd_ps(dout, c, sc, dz2, self.slope)
                 dz1 = self._ps_take(scope, N, F_, hk, hk, dev)
                 with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
-                    psm.conv3x3_ps_dgrad_act(dz2, self._wpk[name + ".conv2.b"], a, dz1, self.slope)
+                    psm.conv3x3_ps_dgrad_act(dz2, self._wpk[name + ".conv2.b"], a, dz1, self.slope, p16=self.p16)
                 dx = torch.empty(N, F_, hk, hk, dtype=F32, device=dev)
                 with self._t("conv3x3_dgrad_unpool", N, hk, fl, self._act_bytes(N, hk, 2 + 0.25 + 1 / 16)):
-                    psm.conv3x3_ps_dgrad_unpool(dz1, self._wpk[name + ".conv1.b"], dout, c, dx, self.slope)
+                    psm.conv3x3_ps_dgrad_unpool(dz1, self._wpk[name + ".conv1.b"], dout, c, dx, self.slope, p16=self.p16)
                 pending_ps.append((a, dz2, name + ".conv2"))
                 pending_ps.append((xin, dz1, name + ".conv1"))
                 dout = dx

@@ -507,9 +507,12 @@ k_block_chain_x3(const ChainArgs a) {
 // scheduling region with the MFMAs: lanes of pad positions write LDS to a per-lane dummy slot and HBM through a buffer
 // descriptor at an out-of-range offset (dropped); a tensor that is not kept has an EMPTY descriptor.  Store counts are
 // therefore exact -- 12 per piece -- and the waits for the weight ring are counted (vmcnt 12 / 24), not drains.
-template <bool BWD>
+// P16 (precision16, see fdet_conv3x3_ps.hip): one MFMA pass on the hi planes; the lo planes are neither moved, kept in
+// LDS nor written: a job is one LDS store and one buffer store, SJ = 4 stores per hand-over group instead of 8.
+template <bool BWD, bool P16 = false>
 __global__ void __launch_bounds__(NTHR, 1)
 k_block_chain_ps(const ChainArgs a) {
+  constexpr int SJ = P16 ? 4 : 8;                               // buffer stores of one group of jobs (NT tiles x 2 halves x planes)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16x8* X = reinterpret_cast<bf16x8*>(smem);                 // [c16 4][hl 2][kh 2][PT] units
   const int PT = a.PT, WP = a.WP;
@@ -545,7 +548,7 @@ k_block_chain_ps(const ChainArgs a) {
   const unsigned wvoff = (unsigned)lane * 16u;
   const unsigned wpiece = (unsigned)((wid >> 1) * A_UNITS + (wid & 1) * 576) * 16u;
   const unsigned wsrc = (unsigned)((wid >> 1) * 4 * A_UNITS + (wid & 1) * 576) * 16u;
-  CH_DMA_W(0, 0, 0)
+  if (!(P16 && wid >= 2)) CH_DMA_W(0, 0, 0)
   {
     f32x4* z = reinterpret_cast<f32x4*>(smem);
     for (int t = tid; t < 16 * PT; t += NTHR) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -570,13 +573,13 @@ k_block_chain_ps(const ChainArgs a) {
   {                                                                                                \
     const float f_[4] = {F0, F1, F2, F3};                                                          \
     unsigned hi_[2], lo_[2];                                                                       \
-    ps_split4(f_, hi_, lo_);                                                                       \
+    if (P16) ps_hi4(f_, hi_); else ps_split4(f_, hi_, lo_);                                        \
     const unsigned ah_ = (unsigned)((((P) * 2 + 0) * 2 + (HH)) * PT) * 16u, al_ = (unsigned)((((P) * 2 + 1) * 2 + (HH)) * PT) * 16u; \
     *reinterpret_cast<u32x2*>(smem + (valid[J] ? ah_ + xw[J] : dmy)) = u32x2{hi_[0], hi_[1]};      \
-    *reinterpret_cast<u32x2*>(smem + (valid[J] ? al_ + xw[J] : dmy)) = u32x2{lo_[0], lo_[1]};      \
+    if (!P16) *reinterpret_cast<u32x2*>(smem + (valid[J] ? al_ + xw[J] : dmy)) = u32x2{lo_[0], lo_[1]}; \
     const unsigned go_ = pso[J] + (unsigned)(4 * ((P) >> 1) + 2 * ((P) & 1) + (HH)) * ps_g;        \
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{hi_[0], hi_[1]}, tgt_rs, go_, 0, 0);               \
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo_[0], lo_[1]}, tgt_rs, go_, ps_lo, 0);           \
+    if (!P16) __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo_[0], lo_[1]}, tgt_rs, go_, ps_lo, 0); \
   }
   // group 0 of a finished tile now; groups 1..3 into the pending registers
 #define CHP_HAND_OVER(V)                                                                           \
@@ -609,7 +612,7 @@ k_block_chain_ps(const ChainArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // first weight chunk landed
   __syncthreads();
-  CH_DMA_W(0, 1, 1)
+  if (!(P16 && wid >= 2)) CH_DMA_W(0, 1, 1)
 
   int tapoff[9];
 #pragma unroll
@@ -631,16 +634,18 @@ k_block_chain_ps(const ChainArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       // weight ring (buffer c & 1 holds chunk c): chunk 1 of a layer was issued before the previous epilogue
-      if (c == 1 || c == 2) CH_DMA_W(L, c + 1, (c & 1) ^ 1)
-      else if (c == 3 && !last) CH_DMA_W(L + 1, 0, 0)
+      if (!(P16 && wid >= 2)) {                                 // P16: the lo-plane waves move nothing
+        if (c == 1 || c == 2) CH_DMA_W(L, c + 1, (c & 1) ^ 1)
+        else if (c == 3 && !last) CH_DMA_W(L + 1, 0, 0)
+      }
       const bf16x8* Ww = Wb + (c & 1) * 2 * A_UNITS + w_off;
       const bf16x8* Xh = X + (c * 2 + 0) * 2 * PT + x_off;
       const bf16x8* Xl = X + (c * 2 + 1) * 2 * PT + x_off;
       bf16x8 wh[2][2], wl[2][2], xh[2][NT], xl[2][NT];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) { wh[0][m] = Ww[m * 32]; wl[0][m] = Ww[A_UNITS + m * 32]; }
+      for (int m = 0; m < 2; ++m) { wh[0][m] = Ww[m * 32]; if (!P16) wl[0][m] = Ww[A_UNITS + m * 32]; }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) { xh[0][j] = Xh[tapoff[0] + j * 32]; xl[0][j] = Xl[tapoff[0] + j * 32]; }
+      for (int j = 0; j < NT; ++j) { xh[0][j] = Xh[tapoff[0] + j * 32]; if (!P16) xl[0][j] = Xl[tapoff[0] + j * 32]; }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
@@ -648,16 +653,17 @@ k_block_chain_ps(const ChainArgs a) {
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             wh[nxt][m] = Ww[(t + 1) * 2 * FCH + m * 32];
-            wl[nxt][m] = Ww[A_UNITS + (t + 1) * 2 * FCH + m * 32];
+            if (!P16) wl[nxt][m] = Ww[A_UNITS + (t + 1) * 2 * FCH + m * 32];
           }
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             xh[nxt][j] = Xh[tapoff[t + 1] + j * 32];
-            xl[nxt][j] = Xl[tapoff[t + 1] + j * 32];
+            if (!P16) xl[nxt][j] = Xl[tapoff[t + 1] + j * 32];
           }
         }
         __builtin_amdgcn_sched_barrier(0);                      // keep the fragment reads one tap ahead of their MFMAs
-        if (CH_DBG & 4) { acc[0][0][0] += (float)wh[cur][0][0] + (float)wl[cur][1][0] + (float)xh[cur][0][0] + (float)xl[cur][1][0] + (float)wh[cur][1][0] + (float)wl[cur][0][0] + (float)xh[cur][1][0] + (float)xl[cur][0][0]; } else {
+        if (CH_DBG & 4) { acc[0][0][0] += (float)wh[cur][0][0] + (float)xh[cur][0][0] + (float)wh[cur][1][0] + (float)xh[cur][1][0]; } else {
+        if (!P16) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -666,6 +672,7 @@ k_block_chain_ps(const ChainArgs a) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int m = 0; m < 2; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cur][m], xh[cur][j], acc[j][m], 0, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -675,6 +682,7 @@ k_block_chain_ps(const ChainArgs a) {
           constexpr int dummy_ = 0; (void)dummy_;
           const int jj = (t - 1) >> 2, hh = ((t - 1) >> 1) & 1;
           CHP_SUB(pend[jj][c][4 * hh], pend[jj][c][4 * hh + 1], pend[jj][c][4 * hh + 2], pend[jj][c][4 * hh + 3], jj, c + 1, hh)
+          if (!P16) {
 #pragma unroll
           for (int i = 0; i < 12; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -682,20 +690,33 @@ k_block_chain_ps(const ChainArgs a) {
             if (i == 8 || i == 9) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             if (i >= 10) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
           }
+          } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            if (i == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (i == 3) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+          }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       // this wave's pieces of the next chunk have landed: everything issued after them is the 8 job stores of this chunk
       // (chunks 0..2) and, after chunk 0, the `young` stores of the previous epilogue (8 of group 0, 16 more for c's hi plane)
-      if (c == 0) { if (young == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (young == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
-      else if (c < 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (c == 0) {
+        if (young == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SJ) : "memory");
+        else if (young == SJ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SJ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SJ + 16) : "memory");
+      }
+      else if (c < 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SJ) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                          // chunk consumed by every wave; next one visible
     }
-    if (!last) CH_DMA_W(L + 1, 1, 1)                            // buffer of chunk 3 is free: next layer's chunk 1
+    if (!last && !(P16 && wid >= 2)) CH_DMA_W(L + 1, 1, 1)      // buffer of chunk 3 is free: next layer's chunk 1
 
     // ---- epilogue arithmetic for the whole tile (in place), then group 0 now and groups 1..3 handed to the next layer
-    young = 8;
+    young = SJ;
     if (CH_DBG & 1) {
     } else if (!BWD) {
       CH_FOR_ALL { const float t = acc[j][m][r]; acc[j][m][r] = t > 0.f ? t : t * a.slope; }
@@ -724,7 +745,7 @@ k_block_chain_ps(const ChainArgs a) {
         } else {
           tgt_rs = CHP_TARGET(a.st2[L]);
           CHP_HAND_OVER(Hreg)
-          young = 24;
+          young = SJ + 16;
         }
       }
     } else {
@@ -766,7 +787,13 @@ int launch_chain(ChainArgs& a, hipStream_t st) {
     return fail(FDET_EINVAL, "block_chain_bf16x3: unsupported map %dx%d (needs 64 channels and H*roundup4(W+1) <= 256)", a.H, a.W);
   if ((size_t)a.N * FCH * a.H * a.W >= ((size_t)1 << 31)) return fail(FDET_EINVAL, "block_chain_bf16x3: tensor too large");
   { const char* e_ = FDET_ENV_ONCE("FDET_CHAIN_STAGGER"); a.stagger = e_ ? atoi(e_) : 0; }
-  if ((a.psio & 1) && a.bwd) {
+  if ((a.psio & 1) && (a.psio & 4) && a.bwd) {             // psio bit 2: precision16
+    { if (int rc_ = set_lds_attr((const void*)k_block_chain_ps<true, true>, (size_t)(lds), __func__)) return rc_; }
+    hipLaunchKernelGGL((k_block_chain_ps<true, true>), dim3(a.N), dim3(NTHR), lds, st, a);
+  } else if ((a.psio & 1) && (a.psio & 4)) {
+    { if (int rc_ = set_lds_attr((const void*)k_block_chain_ps<false, true>, (size_t)(lds), __func__)) return rc_; }
+    hipLaunchKernelGGL((k_block_chain_ps<false, true>), dim3(a.N), dim3(NTHR), lds, st, a);
+  } else if ((a.psio & 1) && a.bwd) {
     { if (int rc_ = set_lds_attr((const void*)k_block_chain_ps<true>, (size_t)(lds), __func__)) return rc_; }
     hipLaunchKernelGGL(k_block_chain_ps<true>, dim3(a.N), dim3(NTHR), lds, st, a);
   } else if (a.psio & 1) {
@@ -854,17 +881,18 @@ int chain_ps_geo(ChainArgs& a, int N, int H, int W) {
 }
 }  // namespace
 
-extern "C" int fdet_block_chain_fwd_ps(const void* x, int x_is_ps, const void* const* h_wpk1, const float* const* h_b1,
-                                       const void* const* h_wpk2, const float* const* h_b2, const float* const* h_scale,
-                                       void* const* h_a_ps, void* const* h_c_ps, void* const* h_out_ps, float* out_last,
-                                       int nblocks, int N, int F, int H, int W, float slope, void* stream) {
+namespace {
+int chain_fwd_ps_run(const void* x, int x_is_ps, const void* const* h_wpk1, const float* const* h_b1,
+                     const void* const* h_wpk2, const float* const* h_b2, const float* const* h_scale,
+                     void* const* h_a_ps, void* const* h_c_ps, void* const* h_out_ps, float* out_last,
+                     int nblocks, int N, int F, int H, int W, float slope, void* stream, bool p16) {
   FDET_REQUIRE(x && h_wpk1 && h_b1 && h_wpk2 && h_b2 && out_last, "block_chain_fwd_ps: null pointer");
   FDET_REQUIRE(nblocks >= 1 && 2 * nblocks <= MAXL && N > 0, "block_chain_fwd_ps: 1..%d blocks (got %d), N=%d", MAXL / 2, nblocks, N);
   FDET_REQUIRE(F == FCH, "block_chain_fwd_ps: 64 channels only (got %d)", F);
   ChainArgs a{};
   FDET_REQUIRE(chain_ps_geo(a, N, H, W), "block_chain_fwd_ps: no PS layout for N=%d %dx%d", N, H, W);
   a.in = reinterpret_cast<const float*>(x); a.nlayers = 2 * nblocks; a.N = N; a.H = H; a.W = W; a.bwd = 0; a.slope = slope;
-  a.psio = 1 | (x_is_ps ? 2 : 0);
+  a.psio = 1 | (x_is_ps ? 2 : 0) | (p16 ? 4 : 0);
   for (int k = 0; k < nblocks; ++k) {
     FDET_REQUIRE(h_wpk1[k] && h_wpk2[k] && h_b1[k] && h_b2[k], "block_chain_fwd_ps: null weights in block %d", k);
     a.w[2 * k] = (const bf16x8*)h_wpk1[k]; a.w[2 * k + 1] = (const bf16x8*)h_wpk2[k];
@@ -877,16 +905,16 @@ extern "C" int fdet_block_chain_fwd_ps(const void* x, int x_is_ps, const void* c
   return launch_chain(a, (hipStream_t)stream);
 }
 
-extern "C" int fdet_block_chain_bwd_ps(const float* dout, const void* const* h_wpk1b, const void* const* h_wpk2b,
-                                       const float* const* h_scale, const void* const* h_a_ps, const void* const* h_c_ps,
-                                       void* const* h_dz1_ps, void* const* h_dz2_ps, float* dx, int nblocks, int N, int F,
-                                       int H, int W, float slope, void* stream) {
+int chain_bwd_ps_run(const float* dout, const void* const* h_wpk1b, const void* const* h_wpk2b,
+                     const float* const* h_scale, const void* const* h_a_ps, const void* const* h_c_ps,
+                     void* const* h_dz1_ps, void* const* h_dz2_ps, float* dx, int nblocks, int N, int F,
+                     int H, int W, float slope, void* stream, bool p16) {
   FDET_REQUIRE(dout && h_wpk1b && h_wpk2b && h_a_ps && h_c_ps && h_dz1_ps && h_dz2_ps && dx, "block_chain_bwd_ps: null pointer");
   FDET_REQUIRE(nblocks >= 1 && 2 * nblocks <= MAXL && N > 0, "block_chain_bwd_ps: 1..%d blocks (got %d), N=%d", MAXL / 2, nblocks, N);
   FDET_REQUIRE(F == FCH, "block_chain_bwd_ps: 64 channels only (got %d)", F);
   ChainArgs a{};
   FDET_REQUIRE(chain_ps_geo(a, N, H, W), "block_chain_bwd_ps: no PS layout for N=%d %dx%d", N, H, W);
-  a.in = dout; a.nlayers = 2 * nblocks; a.N = N; a.H = H; a.W = W; a.bwd = 1; a.slope = slope; a.psio = 1;
+  a.in = dout; a.nlayers = 2 * nblocks; a.N = N; a.H = H; a.W = W; a.bwd = 1; a.slope = slope; a.psio = 1 | (p16 ? 4 : 0);
   for (int j = 0; j < nblocks; ++j) {
     const int k = nblocks - 1 - j;
     FDET_REQUIRE(h_wpk1b[k] && h_wpk2b[k] && h_a_ps[k] && h_c_ps[k] && h_dz1_ps[k] && h_dz2_ps[k], "block_chain_bwd_ps: null pointer in block %d", k);
@@ -905,4 +933,35 @@ extern "C" int fdet_block_chain_bwd_ps(const float* dout, const void* const* h_w
   a.pre_sc = h_scale ? h_scale[nblocks - 1] : nullptr;
   a.pre_st = reinterpret_cast<float*>(h_dz2_ps[nblocks - 1]);
   return launch_chain(a, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int fdet_block_chain_fwd_ps(const void* x, int x_is_ps, const void* const* h_wpk1, const float* const* h_b1,
+                                       const void* const* h_wpk2, const float* const* h_b2, const float* const* h_scale,
+                                       void* const* h_a_ps, void* const* h_c_ps, void* const* h_out_ps, float* out_last,
+                                       int nblocks, int N, int F, int H, int W, float slope, void* stream) {
+  return chain_fwd_ps_run(x, x_is_ps, h_wpk1, h_b1, h_wpk2, h_b2, h_scale, h_a_ps, h_c_ps, h_out_ps, out_last, nblocks, N, F, H, W,
+                          slope, stream, false);
+}
+extern "C" int fdet_block_chain_bwd_ps(const float* dout, const void* const* h_wpk1b, const void* const* h_wpk2b,
+                                       const float* const* h_scale, const void* const* h_a_ps, const void* const* h_c_ps,
+                                       void* const* h_dz1_ps, void* const* h_dz2_ps, float* dx, int nblocks, int N, int F,
+                                       int H, int W, float slope, void* stream) {
+  return chain_bwd_ps_run(dout, h_wpk1b, h_wpk2b, h_scale, h_a_ps, h_c_ps, h_dz1_ps, h_dz2_ps, dx, nblocks, N, F, H, W, slope,
+                          stream, false);
+}
+// precision16 (one bf16 MFMA pass on the hi planes; the tensors kept per block receive their hi plane only)
+extern "C" int fdet_block_chain_fwd_ps_p16(const void* x, int x_is_ps, const void* const* h_wpk1, const float* const* h_b1,
+                                           const void* const* h_wpk2, const float* const* h_b2, const float* const* h_scale,
+                                           void* const* h_a_ps, void* const* h_c_ps, void* const* h_out_ps, float* out_last,
+                                           int nblocks, int N, int F, int H, int W, float slope, void* stream) {
+  return chain_fwd_ps_run(x, x_is_ps, h_wpk1, h_b1, h_wpk2, h_b2, h_scale, h_a_ps, h_c_ps, h_out_ps, out_last, nblocks, N, F, H, W,
+                          slope, stream, true);
+}
+extern "C" int fdet_block_chain_bwd_ps_p16(const float* dout, const void* const* h_wpk1b, const void* const* h_wpk2b,
+                                           const float* const* h_scale, const void* const* h_a_ps, const void* const* h_c_ps,
+                                           void* const* h_dz1_ps, void* const* h_dz2_ps, float* dx, int nblocks, int N, int F,
+                                           int H, int W, float slope, void* stream) {
+  return chain_bwd_ps_run(dout, h_wpk1b, h_wpk2b, h_scale, h_a_ps, h_c_ps, h_dz1_ps, h_dz2_ps, dx, nblocks, N, F, H, W, slope,
+                          stream, true);
 }

@@ -12,6 +12,11 @@
 //     images, every image's halo rows are real zero rows, and row pairs stay pool-aligned.
 // Arithmetic is that of fdet_conv3x3_x3*.hip (a_hi*b_lo + a_lo*b_hi + a_hi*b_hi, fp32 accumulate, the same K order
 // within a chunk), results agree with those kernels to the rounding of the PS format (16 significant bits).
+//
+// P16 instantiations (round 4, the `precision16` mode = the arithmetic of the reference's Trainer(precision=16),
+// train_model.py:50, with bf16 as the 16-bit type): ONE MFMA pass on the hi planes (bf16 activations x bf16 weights, fp32
+// accumulate), only the hi planes are moved by the DMA and only the hi plane of the output is written -- a third of the
+// MFMAs, half the bytes.  The lo planes of a P16 engine's buffers are never written (they stay zero).
 #include "fdet_conv3x3_x3.h"
 #include "fdet_ps.h"
 #include "fdet_ldsdma.h"
@@ -80,7 +85,7 @@ __device__ __forceinline__ void ps_acc_read(const f32x16& acc, const int r, floa
 // stores (hi, lo), 512 contiguous bytes per wave-instruction.  The validity of the position is folded into the offset
 // (out of range = dropped by the hardware): every wave issues exactly two stores per unit, which the counted waits
 // of the main loop rely on.
-template <int MODE>
+template <int MODE, bool P16>
 __device__ __forceinline__ void ps_unit(const f32x16& acc, const int gp, const float (&bza)[4], const float (&bzb)[4],
                                         const u32x2_t (&sg)[2], const float slope, const bool ok, const int ob, const int m,
                                         const int half, const int gstride, const int plane_o_bytes,
@@ -113,25 +118,32 @@ __device__ __forceinline__ void ps_unit(const f32x16& acc, const int gp, const f
     }
   }
   unsigned ha[2], la[2], hb[2], lb[2];
-  ps_split4(za, ha, la);
-  ps_split4(zb, hb, lb);
+  if (P16) {
+    ps_hi4(za, ha);
+    ps_hi4(zb, hb);
+  } else {
+    ps_split4(za, ha, la);
+    ps_split4(zb, hb, lb);
+  }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     auto r1 = __builtin_amdgcn_permlane32_swap(ha[k], hb[k], false, false);
     ha[k] = r1[0]; hb[k] = r1[1];
-    auto r2 = __builtin_amdgcn_permlane32_swap(la[k], lb[k], false, false);
-    la[k] = r2[0]; lb[k] = r2[1];
+    if (!P16) {
+      auto r2 = __builtin_amdgcn_permlane32_swap(la[k], lb[k], false, false);
+      la[k] = r2[0]; lb[k] = r2[1];
+    }
   }
   const int G = 4 * m + 2 * gp + half;
   const unsigned off = ok ? (unsigned)(ob + G * gstride) * 16u : 0x80000000u;
   __builtin_amdgcn_raw_buffer_store_b128(u32x4{ha[0], ha[1], hb[0], hb[1]}, yrs, off, 0, 0);
-  __builtin_amdgcn_raw_buffer_store_b128(u32x4{la[0], la[1], lb[0], lb[1]}, yrs, off, plane_o_bytes, 0);
+  if (!P16) __builtin_amdgcn_raw_buffer_store_b128(u32x4{la[0], la[1], lb[0], lb[1]}, yrs, off, plane_o_bytes, 0);
 }
 
 // WOVEN (forward): the epilogue of tile i runs as 16 "units" spread over the first two chunks of tile i+1, one unit
 // behind each of taps 0..7, its ~65 VALU instructions and two stores placed two or three per MFMA gap by
 // sched_group_barrier; two accumulator sets alternate.  The other modes keep the epilogue at the end of the tile.
-template <int MODE, int WP>
+template <int MODE, int WP, bool P16>
 __global__ void __launch_bounds__(256, 1)
 k_conv3x3_ps(const PsConvArgs p) {
   constexpr bool WOVEN = MODE == PSE_FWD_FULL || MODE == PSE_DGRAD_ACT || MODE == PSE_DGRAD_ADDPOOL;
@@ -189,7 +201,7 @@ k_conv3x3_ps(const PsConvArgs p) {
   const dma_u32x4 xrs = dma_rsrc(p.x - p.img_i, (unsigned)(p.N + 2) * (unsigned)p.img_i * 16u);
   const unsigned wvoff = (unsigned)((wid & 1) * 576 + lane) * 16u;
 #define PS_DMA(C, BS)                                                                              \
-  if (!(PS_DBG & 4)) {                                                                             \
+  if (!(PS_DBG & 4) && !(P16 && wid >= 2)) {                 /* P16: the lo-plane waves move nothing */ \
     const unsigned db_ = lds0 + (unsigned)(BS) * (buf_units * 16);                                 \
     const unsigned ad_ = db_ + (unsigned)((wid >> 1) * PSA + (wid & 1) * 576) * 16u;               \
     _Pragma("unroll") for (int k_ = 0; k_ < ((PS_DBG & 16) ? 0 : 9); ++k_)                          \
@@ -268,7 +280,7 @@ k_conv3x3_ps(const PsConvArgs p) {
 #define PS_OPEN()                                                                                  \
   {                                                                                                \
     if (young == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               \
-    PS_WAITN(8) PS_WAITN(12) PS_WAITN(16) PS_WAITN(32) PS_WAITN(36) PS_WAITN(40) PS_WAITN(44) PS_WAITN(48) PS_WAITN(63) \
+    PS_WAITN(4) PS_WAITN(8) PS_WAITN(12) PS_WAITN(16) PS_WAITN(32) PS_WAITN(36) PS_WAITN(40) PS_WAITN(44) PS_WAITN(48) PS_WAITN(63) \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
     __builtin_amdgcn_s_barrier();                                                                  \
   }
@@ -288,11 +300,11 @@ k_conv3x3_ps(const PsConvArgs p) {
     const int to_ = ((T) / 3) * WP + (T) % 3;                                                      \
     _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_) {                                             \
       ah[F][m_] = Aw[(T) * 128 + m_ * 32];                                                         \
-      al[F][m_] = Aw[PSA + (T) * 128 + m_ * 32];                                                   \
+      if (!P16) al[F][m_] = Aw[PSA + (T) * 128 + m_ * 32];                                         \
     }                                                                                              \
     _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                                             \
       bh[F][n_] = Bw[qn[n_] + to_];                                                                \
-      bl[F][n_] = Bw[2 * PT + qn[n_] + to_];                                                       \
+      if (!P16) bl[F][n_] = Bw[2 * PT + qn[n_] + to_];                                             \
     }                                                                                              \
   }
   // nine taps of one chunk into ACC; FIRST: the tile's first chunk (the first product of every accumulator takes a
@@ -311,9 +323,13 @@ k_conv3x3_ps(const PsConvArgs p) {
         _Pragma("unroll") for (int m = 0; m < 2; ++m)                                              \
           _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                          \
             const f32x16 zero_ = {};                                                               \
-            ACC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[F][m], bl[F][n], ((FIRST) && t == 0) ? zero_ : ACC[m][n], 0, 0, 0); \
-            ACC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[F][m], bh[F][n], ACC[m][n], 0, 0, 0); \
-            ACC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[F][m], bh[F][n], ACC[m][n], 0, 0, 0); \
+            if (P16) {                                                                             \
+              ACC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[F][m], bh[F][n], ((FIRST) && t == 0) ? zero_ : ACC[m][n], 0, 0, 0); \
+            } else {                                                                               \
+              ACC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[F][m], bl[F][n], ((FIRST) && t == 0) ? zero_ : ACC[m][n], 0, 0, 0); \
+              ACC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[F][m], bh[F][n], ACC[m][n], 0, 0, 0); \
+              ACC[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[F][m], bh[F][n], ACC[m][n], 0, 0, 0); \
+            }                                                                                      \
           }                                                                                        \
       }                                                                                            \
       if ((JOB) != 0 && t < 8 && !(PS_DBG & 1)) {                                                  \
@@ -337,12 +353,20 @@ k_conv3x3_ps(const PsConvArgs p) {
           }                                                                                        \
         } else {                                                                                   \
           const int n_ = ((JOB) - 1) * 2 + (t >> 2), m_ = (t >> 1) & 1, gp_ = t & 1;               \
-          ps_unit<MODE>(PREV[WOVEN ? m_ : 0][WOVEN ? n_ : 0], gp_, bz[m_][2 * gp_], bz[m_][2 * gp_ + 1], sgp[n_][m_][gp_], p.slope, okn[n_], ob[n_], m_, \
+          ps_unit<MODE, P16>(PREV[WOVEN ? m_ : 0][WOVEN ? n_ : 0], gp_, bz[m_][2 * gp_], bz[m_][2 * gp_ + 1], sgp[n_][m_][gp_], p.slope, okn[n_], ob[n_], m_, \
                         half, gstride, plane_o_bytes, yrs);                                        \
         }                                                                                          \
       }                                                                                            \
       /* the next tap's twelve fragment reads ride one per MFMA on the first half of this tap, the unit's VALU  */ \
       /* work three per gap, its two stores near the end                                                        */ \
+      if (P16) {   /* 8 MFMAs per tap: the six fragment reads first, the unit's VALU work spread over all gaps */ \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                            \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+          if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+          if ((JOB) != 0) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                       \
+          if ((JOB) != 0 && (i >= 7 || (MODE == PSE_DGRAD_ADDPOOL && i >= 4))) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0); \
+        }                                                                                          \
+      } else {                                                                                     \
       _Pragma("unroll") for (int i = 0; i < 12; ++i) {                                             \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
@@ -353,6 +377,7 @@ k_conv3x3_ps(const PsConvArgs p) {
         if ((JOB) != 0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                         \
         if ((JOB) != 0 && (i >= 10 || (MODE == PSE_DGRAD_ADDPOOL && i >= 8))) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0); \
       }                                                                                            \
+      }                                                                                            \
     }                                                                                              \
     sb ^= 1;                                                                                       \
   }
@@ -361,7 +386,7 @@ k_conv3x3_ps(const PsConvArgs p) {
       MODE == PSE_FWD_POOL ? (int)((size_t)p.N * p.img_p * 16) : (int)((size_t)p.N * 64 * p.H * p.W * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(p.pool_f32, 0, (int)((size_t)p.N * 64 * p.Hp * p.Wp * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(p.route_out, 0, (int)((size_t)p.N * 64 * p.Hp * p.Wp), 0x00020000);
-  const int pool_cnt = MODE == PSE_FWD_POOL ? 4 * (2 * (p.pool_ps != nullptr) + (p.route_out != nullptr) + 8 * (p.pool_f32 != nullptr)) : 63;
+  const int pool_cnt = MODE == PSE_FWD_POOL ? 4 * ((P16 ? 1 : 2) * (p.pool_ps != nullptr) + (p.route_out != nullptr) + 8 * (p.pool_f32 != nullptr)) : 63;
 #define PS_WIN(T)                                                                                  \
     const int rb_ = WP == 64 ? 2 * wid : 4 * wid + 2 * (l31 >> 4);                                 \
     const int v_ = (T) * R + rb_;                                                                  \
@@ -415,9 +440,9 @@ k_conv3x3_ps(const PsConvArgs p) {
         _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                            \
           const u32x2_t* ap = reinterpret_cast<const u32x2_t*>(p.aux + sb0 + (n >> 1) * WP + (n & 1)) + half; \
           sk[m][gp][n][0] = ap[ga * 2];                                                            \
-          sk[m][gp][n][1] = ap[(ga + p.plane_i) * 2];                                              \
+          sk[m][gp][n][1] = P16 ? u32x2_t{0u, 0u} : ap[(ga + p.plane_i) * 2];                      \
           sk[m][gp][n][2] = ap[gb * 2];                                                            \
-          sk[m][gp][n][3] = ap[(gb + p.plane_i) * 2];                                              \
+          sk[m][gp][n][3] = P16 ? u32x2_t{0u, 0u} : ap[(gb + p.plane_i) * 2];                      \
         }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
           const int ch = 32 * m + 16 * gp + 4 * half + i;                                          \
@@ -425,9 +450,12 @@ k_conv3x3_ps(const PsConvArgs p) {
           scv[m][gp][1][i] = (p.scale && okw) ? p.scale[nn * 64 + ch + 8] : 1.f;                   \
         }                                                                                          \
       }                                                                                            \
+    /* values first, then ONE section per output whose branch is uniform for the whole kernel: the number of stores */ \
+    /* between the DMA and the next wait is pool_cnt on every path (tools/audit_vmcnt.py)                            */ \
+    float pvs[2][2][2][4];                                                                         \
+    unsigned rts[2][2][2];                                                                         \
     _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
       _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                           \
-        float pv[2][4];                                                                            \
         unsigned rt[2] = {0u, 0u};                                                                 \
         _Pragma("unroll") for (int ab = 0; ab < 2; ++ab)                                           \
           _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
@@ -443,36 +471,50 @@ k_conv3x3_ps(const PsConvArgs p) {
               const float u_ = z * scv[m][gp][ab][i] + ps_join(sk[m][gp][n][2 * ab][i >> 1], sk[m][gp][n][2 * ab + 1][i >> 1], i & 1); \
               if (u_ > mx || u_ != u_) { mx = u_; arg = n; }   /* first maximum wins, NaN is a maximum (ATen) */ \
             }                                                                                      \
-            pv[ab][i] = mx;                                                                        \
+            pvs[m][gp][ab][i] = mx;                                                                \
             rt[ab] |= (bits | ((unsigned)arg << 4)) << (8 * i);                                    \
           }                                                                                        \
-        if (p.pool_f32) {   /* this lane's own 8 channels: 32m + 16gp + 8ab + 4half + i */          \
+        rts[m][gp][0] = rt[0]; rts[m][gp][1] = rt[1];                                              \
+      }                                                                                            \
+    if (p.pool_f32) {   /* this lane's own 8 channels: 32m + 16gp + 8ab + 4half + i */              \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
+        _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                         \
           const unsigned off = okw ? (unsigned)(((nn * 64 + 32 * m + 16 * gp + 4 * half) * p.Hp + yp) * p.Wp + xp) * 4u : 0x80000000u; \
           _Pragma("unroll") for (int jj = 0; jj < 8; ++jj)                                         \
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv[jj >> 2][jj & 3]), frs, off, \
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pvs[m][gp][jj >> 2][jj & 3]), frs, off, \
                                                   (8 * (jj >> 2) + (jj & 3)) * p.Hp * p.Wp * 4, 0); \
         }                                                                                          \
-        /* half exchange: lanes 0-31 keep group 2gp (channels 0-3 own, 4-7 from the upper half), lanes 32-63 group 2gp+1 */ \
+    }                                                                                              \
+    /* half exchange: lanes 0-31 keep group 2gp (channels 0-3 own, 4-7 from the upper half), lanes 32-63 group 2gp+1 */ \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-          auto r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(pv[0][i]), __float_as_uint(pv[1][i]), false, false); \
+          auto r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(pvs[m][gp][0][i]), __float_as_uint(pvs[m][gp][1][i]), false, false); \
           const unsigned r0_ = r_[0], r1_ = r_[1];   /* (a bit_cast applied to a vector ELEMENT is miscompiled: copy first) */ \
-          pv[0][i] = __uint_as_float(r0_); pv[1][i] = __uint_as_float(r1_);                        \
+          pvs[m][gp][0][i] = __uint_as_float(r0_); pvs[m][gp][1][i] = __uint_as_float(r1_);        \
         }                                                                                          \
-        { auto r_ = __builtin_amdgcn_permlane32_swap(rt[0], rt[1], false, false); rt[0] = r_[0]; rt[1] = r_[1]; } \
-        const int G = 4 * m + 2 * gp + half;                                                       \
-        if (p.pool_ps) {                                                                           \
+        { auto r_ = __builtin_amdgcn_permlane32_swap(rts[m][gp][0], rts[m][gp][1], false, false); rts[m][gp][0] = r_[0]; rts[m][gp][1] = r_[1]; } \
+      }                                                                                            \
+    if (p.pool_ps) {                                                                               \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
+        _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                         \
+          const int G = 4 * m + 2 * gp + half;                                                     \
           unsigned ha[2], la[2], hb[2], lb2[2];                                                    \
-          ps_split4(pv[0], ha, la);                                                                \
-          ps_split4(pv[1], hb, lb2);                                                               \
+          if (P16) { ps_hi4(pvs[m][gp][0], ha); ps_hi4(pvs[m][gp][1], hb); }                       \
+          else { ps_split4(pvs[m][gp][0], ha, la); ps_split4(pvs[m][gp][1], hb, lb2); }            \
           const unsigned off = okw ? (unsigned)(nn * p.img_p + (G * p.HPp + yp) * p.WPp + xp + 1) * 16u : 0x80000000u; \
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{ha[0], ha[1], hb[0], hb[1]}, prs, off, 0, 0); \
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{la[0], la[1], lb2[0], lb2[1]}, prs, off, p.plane_p * 16, 0); \
+          if (!P16) __builtin_amdgcn_raw_buffer_store_b128(u32x4{la[0], la[1], lb2[0], lb2[1]}, prs, off, p.plane_p * 16, 0); \
         }                                                                                          \
-        if (p.route_out) {                                                                         \
+    }                                                                                              \
+    if (p.route_out) {                                                                             \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
+        _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                         \
+          const int G = 4 * m + 2 * gp + half;                                                     \
           const unsigned off = okw ? (unsigned)(((nn * 8 + G) * p.Hp + yp) * p.Wp + xp) * 8u : 0x80000000u; \
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{rt[0], rt[1]}, rrs, off, 0, 0);            \
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{rts[m][gp][0], rts[m][gp][1]}, rrs, off, 0, 0); \
         }                                                                                          \
-      }                                                                                            \
+    }                                                                                              \
   } else {                                                                                         \
     _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
       _Pragma("unroll") for (int n = 0; n < 4; ++n) ps_keep(ACC[m][n]);                            \
@@ -522,7 +564,7 @@ k_conv3x3_ps(const PsConvArgs p) {
     _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                  \
       _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
         _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                           \
-          ps_unit<MODE>(ACC[m][n], gp, bz[m][2 * gp], bz[m][2 * gp + 1], sgp[n][m][gp], p.slope,  \
+          ps_unit<MODE, P16>(ACC[m][n], gp, bz[m][2 * gp], bz[m][2 * gp + 1], sgp[n][m][gp], p.slope,  \
                         okn[n], ob[n], m, half, gstride, plane_o_bytes, yrs);                      \
   } else {                                                                                         \
     _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
@@ -534,7 +576,7 @@ k_conv3x3_ps(const PsConvArgs p) {
     PS_OPEN()                                                                                      \
     PS_NEXT(0)                                                                                     \
     PS_BODY(ACC, 1, (WOVEN ? 1 : 0), PREV)                                                         \
-    young = (WOVEN && !(PS_DBG & 1)) ? (MODE == PSE_DGRAD_ADDPOOL ? 32 : 16) : 0;                  \
+    young = (WOVEN && !(PS_DBG & 1)) ? (MODE == PSE_DGRAD_ADDPOOL ? 32 : (P16 ? 8 : 16)) : 0;      \
     PS_OPEN()                                                                                      \
     PS_NEXT(1)                                                                                     \
     PS_BODY(ACC, 0, (WOVEN ? 2 : 0), PREV)                                                         \
@@ -603,8 +645,8 @@ int ps_num_cus() {
   return ncu;
 }
 
-// One translation unit per (mode, row width): the woven kernels take a minute or more each to compile, so the Makefile
-// builds this source nine times -- -DPS_TU=<2*mode + (WP == 64)> emits ONE kernel instantiation behind
+// One translation unit per (mode, row width, precision): the woven kernels take a minute or more each to compile, so the
+// Makefile builds this source 17 times -- -DPS_TU=<8*P16 + 2*mode + (WP == 64)> emits ONE kernel instantiation behind
 // fdet_ps_launch_<n>(), and the plain build keeps the host logic and the C-ABI.
 #ifndef PS_TU
 #define PS_TU (-1)
@@ -612,41 +654,44 @@ int ps_num_cus() {
 #define PS_CAT_(a, b) a##b
 #define PS_CAT(a, b) PS_CAT_(a, b)
 #define PS_TU_NAME PS_CAT(fdet_ps_launch_, PS_TU)
-template <int MODE, int WP>
+template <int MODE, int WP, bool P16>
 int launch_ps(const PsConvArgs& p, size_t lds, int grid, hipStream_t st) {
   static bool attr_set = false;
   constexpr int lds_max = 2 * (2 * PSA + 4 * 648) * 16;  // the 64-slot geometry
   if (!attr_set) {
-    if ((int)lds > lds_max || hipFuncSetAttribute((const void*)k_conv3x3_ps<MODE, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) {
+    if ((int)lds > lds_max || hipFuncSetAttribute((const void*)k_conv3x3_ps<MODE, WP, P16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) {
       (void)hipGetLastError();
       return fail(FDET_ELAUNCH, "conv3x3_ps: cannot reserve %zu bytes of LDS", lds);
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_conv3x3_ps<MODE, WP>), dim3(grid), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((k_conv3x3_ps<MODE, WP, P16>), dim3(grid), dim3(256), lds, st, p);
   return check_launch("fdet_conv3x3_ps");
 }
 
 }  // namespace
 #define PS_DECL_LAUNCH(N) extern "C" int fdet_ps_launch_##N(const void* args, size_t lds, int grid, void* stream);
 PS_DECL_LAUNCH(0) PS_DECL_LAUNCH(1) PS_DECL_LAUNCH(2) PS_DECL_LAUNCH(3) PS_DECL_LAUNCH(4) PS_DECL_LAUNCH(5) PS_DECL_LAUNCH(6) PS_DECL_LAUNCH(7)
+PS_DECL_LAUNCH(8) PS_DECL_LAUNCH(9) PS_DECL_LAUNCH(10) PS_DECL_LAUNCH(11) PS_DECL_LAUNCH(12) PS_DECL_LAUNCH(13) PS_DECL_LAUNCH(14) PS_DECL_LAUNCH(15)
 #if PS_TU >= 0
 extern "C" int PS_TU_NAME(const void* args, size_t lds, int grid, void* stream) {
-  return launch_ps<PS_TU / 2, (PS_TU & 1) ? 64 : 32>(*reinterpret_cast<const PsConvArgs*>(args), lds, grid, (hipStream_t)stream);
+  return launch_ps<(PS_TU & 7) / 2, (PS_TU & 1) ? 64 : 32, (PS_TU >= 8)>(*reinterpret_cast<const PsConvArgs*>(args), lds, grid, (hipStream_t)stream);
 }
 #endif
 namespace {
 #if PS_TU == -1
 typedef int (*ps_launch_fn)(const void*, size_t, int, void*);
-const ps_launch_fn PS_LAUNCHERS[8] = {fdet_ps_launch_0, fdet_ps_launch_1, fdet_ps_launch_2, fdet_ps_launch_3,
-                                      fdet_ps_launch_4, fdet_ps_launch_5, fdet_ps_launch_6, fdet_ps_launch_7};
+const ps_launch_fn PS_LAUNCHERS[16] = {fdet_ps_launch_0, fdet_ps_launch_1, fdet_ps_launch_2, fdet_ps_launch_3,
+                                       fdet_ps_launch_4, fdet_ps_launch_5, fdet_ps_launch_6, fdet_ps_launch_7,
+                                       fdet_ps_launch_8, fdet_ps_launch_9, fdet_ps_launch_10, fdet_ps_launch_11,
+                                       fdet_ps_launch_12, fdet_ps_launch_13, fdet_ps_launch_14, fdet_ps_launch_15};
 struct PsPoolIO {
   const float* scale = nullptr; void* pool_ps = nullptr; float* pool_f32 = nullptr; unsigned char* route_out = nullptr;
   const float* dout = nullptr; const unsigned char* route_in = nullptr; float* dx_f32 = nullptr;
 };
 
 int run_ps(int mode, const void* x, const void* wpk, const float* bias, const void* aux, void* y, const PsPoolIO& io, int N,
-           int Cin, int Cout, int H, int W, float slope, hipStream_t st) {
+           int Cin, int Cout, int H, int W, float slope, hipStream_t st, bool p16 = false) {
   PsGeo gi, go, gp;
   const bool pooled = mode == PSE_FWD_POOL || mode == PSE_DGRAD_ADDPOOL;
   FDET_REQUIRE(x && wpk && (y || pooled), "conv3x3_ps: null pointer");
@@ -698,7 +743,7 @@ int run_ps(int mode, const void* x, const void* wpk, const float* bias, const vo
       FDET_REQUIRE(io.dout && io.route_in && io.dx_f32, "conv3x3_ps_dgrad_unpool: dout, route and dx are required");
       break;
   }
-  return PS_LAUNCHERS[2 * mode + (w64 ? 1 : 0)](&p, lds, grid, (void*)st);
+  return PS_LAUNCHERS[(p16 ? 8 : 0) + 2 * mode + (w64 ? 1 : 0)](&p, lds, grid, (void*)st);
 }
 #endif  // PS_TU == -1
 
@@ -738,6 +783,32 @@ extern "C" int fdet_conv3x3_ps_dgrad_unpool(const void* dz_ps, const void* wpk, 
   PsPoolIO io;
   io.dout = dout_pooled; io.route_in = route8; io.dx_f32 = dx;
   return run_ps(PSE_DGRAD_ADDPOOL, dz_ps, wpk, nullptr, nullptr, nullptr, io, N, Cout, Cin, H, W, slope, (hipStream_t)stream);
+}
+
+// ---- precision16 (round 4): the same four operations with ONE bf16 MFMA pass on the hi planes (bf16 activations and
+// weights, fp32 accumulate and epilogue arithmetic), hi planes only moved and written.  The arithmetic of the reference's
+// Trainer(precision=16) (train_model.py:50) with bf16 as the 16-bit type.
+extern "C" int fdet_conv3x3_ps_fwd_p16(const void* x_ps, const void* wpk, const float* bias, void* y_ps, int N, int Cin,
+                                       int Cout, int H, int W, float slope, void* stream) {
+  return run_ps(PSE_FWD_FULL, x_ps, wpk, bias, nullptr, y_ps, PsPoolIO{}, N, Cin, Cout, H, W, slope, (hipStream_t)stream, true);
+}
+extern "C" int fdet_conv3x3_ps_dgrad_act_p16(const void* dz_ps, const void* wpk, const void* act_ps, void* dx_ps, int N,
+                                             int Cin, int Cout, int H, int W, float slope, void* stream) {
+  return run_ps(PSE_DGRAD_ACT, dz_ps, wpk, nullptr, act_ps, dx_ps, PsPoolIO{}, N, Cout, Cin, H, W, slope, (hipStream_t)stream, true);
+}
+extern "C" int fdet_conv3x3_ps_fwd_pool_p16(const void* x_ps, const void* wpk, const float* bias, const void* skip_ps,
+                                            const float* drop_scale, void* pool_ps, float* pool_f32, unsigned char* route8,
+                                            int N, int Cin, int Cout, int H, int W, float slope, void* stream) {
+  PsPoolIO io;
+  io.scale = drop_scale; io.pool_ps = pool_ps; io.pool_f32 = pool_f32; io.route_out = route8;
+  return run_ps(PSE_FWD_POOL, x_ps, wpk, bias, skip_ps, nullptr, io, N, Cin, Cout, H, W, slope, (hipStream_t)stream, true);
+}
+extern "C" int fdet_conv3x3_ps_dgrad_unpool_p16(const void* dz_ps, const void* wpk, const float* dout_pooled,
+                                                const unsigned char* route8, float* dx, int N, int Cin, int Cout, int H, int W,
+                                                float slope, void* stream) {
+  PsPoolIO io;
+  io.dout = dout_pooled; io.route_in = route8; io.dx_f32 = dx;
+  return run_ps(PSE_DGRAD_ADDPOOL, dz_ps, wpk, nullptr, nullptr, nullptr, io, N, Cout, Cin, H, W, slope, (hipStream_t)stream, true);
 }
 
 #endif  // PS_TU == -1

@@ -58,6 +58,15 @@ __device__ __forceinline__ void ps_split4(const float (&f)[4], unsigned (&hi)[2]
     lo[k] = __builtin_bit_cast(unsigned, l);
   }
 }
+// the hi parts only (precision16: bf16 activations, RNE): hi[0] = {x0,x1}, hi[1] = {x2,x3}
+__device__ __forceinline__ void ps_hi4(const float (&f)[4], unsigned (&hi)[2]) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const bf16x2_t h = {(__bf16)f[2 * k], (__bf16)f[2 * k + 1]};
+    hi[k] = __builtin_bit_cast(unsigned, h);
+  }
+}
 // value of element k (0 / 1) of a packed hi / lo dword pair
 __device__ __forceinline__ float ps_join(unsigned hi, unsigned lo, int k) {
   const float h = __builtin_bit_cast(float, k ? (hi & 0xffff0000u) : (hi << 16));

@@ -69,7 +69,8 @@ __host__ __device__ constexpr int x_off(int S, int ky, int WP) {
   return 16 * S + (ky - 1) * WP < 0 ? 16 * S + (ky - 1) * WP + 64 : (16 * S + (ky - 1) * WP >= 64 ? 16 * S + (ky - 1) * WP - 64 : 16 * S + (ky - 1) * WP);
 }
 
-template <int WP, bool FL1>
+// P16 (precision16, see fdet_conv3x3_ps.hip): one MFMA pass on the hi planes; only their pieces are moved.
+template <int WP, bool FL1, bool P16 = false>
 __global__ void __launch_bounds__(256, 1)
 k_wgrad3x3_ps(const PsWgArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,7 +119,7 @@ k_wgrad3x3_ps(const PsWgArgs a) {
   }
   // wave w moves arrays 4w .. 4w+3 of both tensors: x line LX into ring slot SX, dz line LZ into ring slot SZ
 #define WG_ISSUE(LX, SX, LZ, SZ)                                                                   \
-  {                                                                                                \
+  if (!(P16 && wid >= 2)) {                                  /* P16: arrays 8..15 are the lo planes */ \
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                             \
       const int ai_ = 4 * wid + k_;                                                                \
       WG_PIECE(xrs, LX, ai_, ai_ * XA + (SX) * 64)                                                  \
@@ -131,7 +132,7 @@ k_wgrad3x3_ps(const PsWgArgs a) {
 #define XS(D) ((sx + (D)) % XL)
   WG_ISSUE(l0 - 1, XS(0), l0, sz)
   WG_ISSUE(l0, XS(1), l0 + 1, (sz + 1) % ZL)
-  {
+  if (!(P16 && wid >= 2)) {
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {
       const int ai_ = 4 * wid + k_;
       WG_PIECE(xrs, l0 + 1, ai_, ai_ * XA + XS(2) * 64)
@@ -145,7 +146,7 @@ k_wgrad3x3_ps(const PsWgArgs a) {
 #define WG_FRAGS(F, S, ZB, XB0, XB1, XB2)                                                          \
   {                                                                                                \
     _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                               \
-      _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                          \
+      _Pragma("unroll") for (int pl_ = 0; pl_ < (P16 ? 1 : 2); ++pl_)                              \
         _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                         \
           const u32x2_t z_ = (WG_DBG & 4) ? u32x2_t{0x3f803f80u + (unsigned)lane, 0x40004000u} : tr2(ZB, pl_ * ZPL + (16 * (S) + 4 * h_ - (k_ - 1)) * 16); \
           zf[F][k_][pl_][2 * h_] = z_[0]; zf[F][k_][pl_][2 * h_ + 1] = z_[1];                      \
@@ -207,8 +208,10 @@ k_wgrad3x3_ps(const PsWgArgs a) {
             const bf16x8 ah = __builtin_bit_cast(bf16x8, zf[F][kx][0]), al = __builtin_bit_cast(bf16x8, zf[F][kx][1]);
             const bf16x8 bh = __builtin_bit_cast(bf16x8, xf[F][ky][0]), bl = __builtin_bit_cast(bf16x8, xf[F][ky][1]);
             if (!(WG_DBG & 2)) {
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+              if (!P16) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+              }
               acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
             }
           }
@@ -217,7 +220,7 @@ k_wgrad3x3_ps(const PsWgArgs a) {
         {
           const bf16x2_t sel = as_bf16x2((s & 1) ? bsel1 : bsel0);
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
+          for (int pl = 0; pl < (P16 ? 1 : 2); ++pl) {
             const u32x4_t zv = zf[F][1][pl];
             bsum = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(zv[0]), sel, bsum, false);
             bsum = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(zv[1]), sel, bsum, false);
@@ -226,13 +229,19 @@ k_wgrad3x3_ps(const PsWgArgs a) {
           }
         }
         // the next step's 24 transposed reads ride one per MFMA
-        if (s < 3 || FL1) {
+        if ((s < 3 || FL1) && !P16) {
 #pragma unroll
           for (int i = 0; i < 24; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
           __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        } else if (s < 3 || FL1) {                           // P16: 9 MFMAs, 12 transposed reads
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          }
         }
       }
     }
@@ -347,9 +356,9 @@ extern "C" size_t fdet_conv3x3_wgrad_ps_ws_bytes(int L, int N, int C, int H, int
 
 // dW[l] [64,64,3,3], db[l] [64] of L same-shape 64-channel layers from PS tensors x[l], dz[l] (image-0 pointers; host
 // arrays of device pointers)
-extern "C" int fdet_conv3x3_wgrad_ps_batched(const void* const* h_x, const void* const* h_dz, float* const* h_dW,
-                                             float* const* h_db, int L, int N, int C, int H, int W, void* ws,
-                                             size_t ws_bytes, void* stream) {
+namespace {
+int wgrad_ps_run(const void* const* h_x, const void* const* h_dz, float* const* h_dW, float* const* h_db, int L, int N, int C,
+                 int H, int W, void* ws, size_t ws_bytes, void* stream, bool p16) {
   PsGeo g;
   int nslab = 0, lpw = 0;
   FDET_REQUIRE(h_x && h_dz && h_dW && h_db && ws, "conv3x3_wgrad_ps: null pointer");
@@ -387,9 +396,14 @@ extern "C" int fdet_conv3x3_wgrad_ps_batched(const void* const* h_x, const void*
     hipLaunchKernelGGL(kern, dim3(nslab, L), dim3(256), lds, st, a);
     return FDET_OK;
   };
-  static bool d64a = false, d64b = false, d32a = false, d32b = false, d16a = false, d16b = false;
+  static bool d64a = false, d64b = false, d32a = false, d32b = false, d16a = false, d16b = false, d64p = false, d32p = false, d16p = false;
   int rc0;
-  if (g.WP == 64) rc0 = fl1 ? go(k_wgrad3x3_ps<64, true>, d64a) : go(k_wgrad3x3_ps<64, false>, d64b);
+  if (p16) {
+    if (g.WP == 64) rc0 = go(k_wgrad3x3_ps<64, true, true>, d64p);
+    else if (g.WP == 16) rc0 = go(k_wgrad3x3_ps<16, true, true>, d16p);
+    else rc0 = go(k_wgrad3x3_ps<32, true, true>, d32p);
+  }
+  else if (g.WP == 64) rc0 = fl1 ? go(k_wgrad3x3_ps<64, true>, d64a) : go(k_wgrad3x3_ps<64, false>, d64b);
   else if (g.WP == 16) rc0 = fl1 ? go(k_wgrad3x3_ps<16, true>, d16a) : go(k_wgrad3x3_ps<16, false>, d16b);
   else rc0 = fl1 ? go(k_wgrad3x3_ps<32, true>, d32a) : go(k_wgrad3x3_ps<32, false>, d32b);
   if (rc0 != FDET_OK) return rc0;
@@ -397,4 +411,18 @@ extern "C" int fdet_conv3x3_wgrad_ps_batched(const void* const* h_x, const void*
   if (rc != FDET_OK) return rc;
   hipLaunchKernelGGL(k_wgrad_ps_reduce, dim3(9 * 64 + 1, L), dim3(256), 0, st, a.ws, a.wsb, nslab, red);
   return check_launch("fdet_conv3x3_wgrad_ps_batched(reduce)");
+}
+}  // namespace
+
+extern "C" int fdet_conv3x3_wgrad_ps_batched(const void* const* h_x, const void* const* h_dz, float* const* h_dW,
+                                             float* const* h_db, int L, int N, int C, int H, int W, void* ws,
+                                             size_t ws_bytes, void* stream) {
+  return wgrad_ps_run(h_x, h_dz, h_dW, h_db, L, N, C, H, W, ws, ws_bytes, stream, false);
+}
+
+// precision16: one bf16 MFMA pass on the hi planes of x / dz (fp32 accumulate, fp32 dW / db)
+extern "C" int fdet_conv3x3_wgrad_ps_batched_p16(const void* const* h_x, const void* const* h_dz, float* const* h_dW,
+                                                 float* const* h_db, int L, int N, int C, int H, int W, void* ws,
+                                                 size_t ws_bytes, void* stream) {
+  return wgrad_ps_run(h_x, h_dz, h_dW, h_db, L, N, C, H, W, ws, ws_bytes, stream, true);
 }

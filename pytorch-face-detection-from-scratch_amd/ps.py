@@ -61,18 +61,23 @@ def _same(a: PsTensor, shape, name):
         raise ValueError(f"{name}: expected a PsTensor of shape {tuple(shape)}, got {getattr(a, 'shape', type(a))}")
 
 
-def conv3x3_ps_fwd(x: PsTensor, wpk: torch.Tensor, bias: torch.Tensor, y: PsTensor, slope: float = 0.2) -> None:
+def _fn(name: str, p16: bool):
+    """The C-ABI entry point `name`, or its one-pass `_p16` twin (precision16: bf16 hi planes only, include/fdet.h)."""
+    return getattr(lib(), name + "_p16" if p16 else name)
+
+
+def conv3x3_ps_fwd(x: PsTensor, wpk: torch.Tensor, bias: torch.Tensor, y: PsTensor, slope: float = 0.2, p16: bool = False) -> None:
     """y = LeakyReLU(conv3x3(x) + bias) on PS tensors; wpk: forward panel of pack_conv3x3_weights(x3=True)."""
     N, cin, H, W = x.shape
     cout = int(bias.shape[0])
     _same(y, (N, cout, H, W), "conv3x3_ps_fwd: y")
     if wpk.numel() != cout * cin * 9:
         raise ValueError("conv3x3_ps_fwd: packed weight size does not match (Cout,Cin)")
-    check(lib().fdet_conv3x3_ps_fwd(x.data, ptr(wpk), ptr(bias), y.data, N, cin, cout, H, W, float(slope), stream()),
+    check(_fn("fdet_conv3x3_ps_fwd", p16)(x.data, ptr(wpk), ptr(bias), y.data, N, cin, cout, H, W, float(slope), stream()),
           "fdet_conv3x3_ps_fwd")
 
 
-def conv3x3_ps_dgrad_act(dz: PsTensor, wpk_bwd: torch.Tensor, act: PsTensor, dx: PsTensor, slope: float = 0.2) -> None:
+def conv3x3_ps_dgrad_act(dz: PsTensor, wpk_bwd: torch.Tensor, act: PsTensor, dx: PsTensor, slope: float = 0.2, p16: bool = False) -> None:
     """dx = conv3x3^T(dz) * LeakyReLU'(act) on PS tensors; wpk_bwd: backward panel."""
     N, cout, H, W = dz.shape
     cin = dx.shape[1]
@@ -80,15 +85,15 @@ def conv3x3_ps_dgrad_act(dz: PsTensor, wpk_bwd: torch.Tensor, act: PsTensor, dx:
     _same(act, (N, cin, H, W), "conv3x3_ps_dgrad_act: act")
     if wpk_bwd.numel() != cout * cin * 9:
         raise ValueError("conv3x3_ps_dgrad_act: packed weight size does not match (Cout,Cin)")
-    check(lib().fdet_conv3x3_ps_dgrad_act(dz.data, ptr(wpk_bwd), act.data, dx.data, N, cin, cout, H, W, float(slope),
-                                          stream()), "fdet_conv3x3_ps_dgrad_act")
+    check(_fn("fdet_conv3x3_ps_dgrad_act", p16)(dz.data, ptr(wpk_bwd), act.data, dx.data, N, cin, cout, H, W, float(slope),
+                                                stream()), "fdet_conv3x3_ps_dgrad_act")
 
 
 def conv3x3_wgrad_ps_ws_bytes(L: int, N: int, C: int, H: int, W: int) -> int:
     return int(lib().fdet_conv3x3_wgrad_ps_ws_bytes(L, N, C, H, W))
 
 
-def conv3x3_wgrad_ps_batched(xs, dzs, dWs, dbs, ws: torch.Tensor) -> None:
+def conv3x3_wgrad_ps_batched(xs, dzs, dWs, dbs, ws: torch.Tensor, p16: bool = False) -> None:
     """dWs[l] (64,64,3,3), dbs[l] (64,) = weight / bias gradients of L same-shape layers from PS operands."""
     import ctypes
     L = len(xs)
@@ -99,9 +104,9 @@ def conv3x3_wgrad_ps_batched(xs, dzs, dWs, dbs, ws: torch.Tensor) -> None:
         if tuple(dW.shape) != (C, C, 3, 3) or tuple(db.shape) != (C,):
             raise ValueError("conv3x3_wgrad_ps: dW / db shapes")
     arr = ctypes.c_void_p * L
-    check(lib().fdet_conv3x3_wgrad_ps_batched(arr(*[x.data for x in xs]), arr(*[z.data for z in dzs]),
-                                              arr(*[ptr(t) for t in dWs]), arr(*[ptr(t) for t in dbs]), L, N, C, H, W,
-                                              ptr(ws), ws.numel() * 4, stream()), "fdet_conv3x3_wgrad_ps_batched")
+    check(_fn("fdet_conv3x3_wgrad_ps_batched", p16)(arr(*[x.data for x in xs]), arr(*[z.data for z in dzs]),
+                                                    arr(*[ptr(t) for t in dWs]), arr(*[ptr(t) for t in dbs]), L, N, C, H, W,
+                                                    ptr(ws), ws.numel() * 4, stream()), "fdet_conv3x3_wgrad_ps_batched")
 
 
 def route8_like(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
@@ -110,7 +115,7 @@ def route8_like(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
 
 
 def conv3x3_ps_fwd_pool(x: PsTensor, wpk, bias, skip: PsTensor, drop_scale, pool_ps: PsTensor = None,
-                        pool_f32: torch.Tensor = None, route8: torch.Tensor = None, slope: float = 0.2) -> None:
+                        pool_f32: torch.Tensor = None, route8: torch.Tensor = None, slope: float = 0.2, p16: bool = False) -> None:
     """pooled = maxpool2x2(lrelu(conv(x)+bias) * drop_scale + skip) -> pool_ps and / or pool_f32; route8: routing bytes."""
     N, cin, H, W = x.shape
     cout = int(bias.shape[0])
@@ -125,9 +130,9 @@ def conv3x3_ps_fwd_pool(x: PsTensor, wpk, bias, skip: PsTensor, drop_scale, pool
         raise ValueError("conv3x3_ps_fwd_pool: drop_scale shape")
     if wpk.numel() != cout * cin * 9:
         raise ValueError("conv3x3_ps_fwd_pool: packed weight size does not match (Cout,Cin)")
-    check(lib().fdet_conv3x3_ps_fwd_pool(x.data, ptr(wpk), ptr(bias), skip.data, ptr(drop_scale),
-                                         pool_ps.data if pool_ps is not None else None, ptr(pool_f32),
-                                         ptr(route8, torch.uint8), N, cin, cout, H, W, float(slope), stream()),
+    check(_fn("fdet_conv3x3_ps_fwd_pool", p16)(x.data, ptr(wpk), ptr(bias), skip.data, ptr(drop_scale),
+                                               pool_ps.data if pool_ps is not None else None, ptr(pool_f32),
+                                               ptr(route8, torch.uint8), N, cin, cout, H, W, float(slope), stream()),
           "fdet_conv3x3_ps_fwd_pool")
 
 
@@ -141,7 +146,7 @@ def pool_route_bwd_ps(dout_pooled: torch.Tensor, route8: torch.Tensor, drop_scal
 
 
 def conv3x3_ps_dgrad_unpool(dz: PsTensor, wpk_bwd, dout_pooled: torch.Tensor, route8: torch.Tensor, dx: torch.Tensor,
-                            slope: float = 0.2) -> None:
+                            slope: float = 0.2, p16: bool = False) -> None:
     """dx (fp32 NCHW) = conv3x3^T(dz) + unpool(dout_pooled) through the routing bytes."""
     N, cout, H, W = dz.shape
     cin = dx.shape[1]
@@ -150,8 +155,8 @@ def conv3x3_ps_dgrad_unpool(dz: PsTensor, wpk_bwd, dout_pooled: torch.Tensor, ro
         raise ValueError("conv3x3_ps_dgrad_unpool: shapes")
     if wpk_bwd.numel() != cout * cin * 9:
         raise ValueError("conv3x3_ps_dgrad_unpool: packed weight size does not match (Cout,Cin)")
-    check(lib().fdet_conv3x3_ps_dgrad_unpool(dz.data, ptr(wpk_bwd), ptr(dout_pooled), ptr(route8, torch.uint8), ptr(dx),
-                                             N, cin, cout, H, W, float(slope), stream()), "fdet_conv3x3_ps_dgrad_unpool")
+    check(_fn("fdet_conv3x3_ps_dgrad_unpool", p16)(dz.data, ptr(wpk_bwd), ptr(dout_pooled), ptr(route8, torch.uint8), ptr(dx),
+                                                   N, cin, cout, H, W, float(slope), stream()), "fdet_conv3x3_ps_dgrad_unpool")
 
 
 def stem_fwd_ps(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, y: PsTensor, k: int, stride: int, pad: int) -> None:
@@ -171,7 +176,8 @@ def _ps_ptr_array(ts):
     return (ctypes.c_void_p * len(ts))(*[(t.data if t is not None else None) for t in ts])
 
 
-def block_chain_fwd_ps(x, wpk1, b1, wpk2, b2, scales, a_ps, c_ps, out_ps, out_last: torch.Tensor, slope: float = 0.2) -> None:
+def block_chain_fwd_ps(x, wpk1, b1, wpk2, b2, scales, a_ps, c_ps, out_ps, out_last: torch.Tensor, slope: float = 0.2,
+                       p16: bool = False) -> None:
     """The LDS-resident residual-block chain (fdet_block_chain_fwd_ps) keeping a_k / c_k / block outputs as PS tensors.
     x: PsTensor or fp32 NCHW; a_ps, c_ps: lists of nblocks PsTensors (or None: not kept); out_ps: nblocks-1 PsTensors
     (or None); out_last: fp32 NCHW output of the last block.  c_ps[k] only receives its hi plane (its signs)."""
@@ -192,14 +198,14 @@ def block_chain_fwd_ps(x, wpk1, b1, wpk2, b2, scales, a_ps, c_ps, out_ps, out_la
             for t in lst:
                 if t is not None:
                     _same(t, (N, C, H, W), "block_chain_fwd_ps: " + nm)
-    check(lib().fdet_block_chain_fwd_ps(x.data if x_is_ps else ptr(x), int(x_is_ps), _ptr_array(wpk1), _ptr_array(b1),
+    check(_fn("fdet_block_chain_fwd_ps", p16)(x.data if x_is_ps else ptr(x), int(x_is_ps), _ptr_array(wpk1), _ptr_array(b1),
                                         _ptr_array(wpk2), _ptr_array(b2), _ptr_array(scales), _ps_ptr_array(a_ps),
                                         _ps_ptr_array(c_ps), _ps_ptr_array(out_ps), ptr(out_last), nb, N, C, H, W,
                                         float(slope), stream()), "fdet_block_chain_fwd_ps")
 
 
 def block_chain_bwd_ps(dout: torch.Tensor, wpk1b, wpk2b, scales, a_ps, c_ps, dz1_ps, dz2_ps, dx: torch.Tensor,
-                       slope: float = 0.2) -> None:
+                       slope: float = 0.2, p16: bool = False) -> None:
     """Data-gradient chain of the same blocks (fdet_block_chain_bwd_ps): fills dz1_ps[k], dz2_ps[k] (PS) and dx (fp32)."""
     from .hotpath import _ptr_array
     nb = len(wpk1b)
@@ -211,7 +217,7 @@ def block_chain_bwd_ps(dout: torch.Tensor, wpk1b, wpk2b, scales, a_ps, c_ps, dz1
             _same(t, (N, C, H, W), "block_chain_bwd_ps: " + nm)
     if tuple(dx.shape) != (N, C, H, W):
         raise ValueError("block_chain_bwd_ps: dx shape mismatch")
-    check(lib().fdet_block_chain_bwd_ps(ptr(dout), _ptr_array(wpk1b), _ptr_array(wpk2b), _ptr_array(scales),
+    check(_fn("fdet_block_chain_bwd_ps", p16)(ptr(dout), _ptr_array(wpk1b), _ptr_array(wpk2b), _ptr_array(scales),
                                         _ps_ptr_array(a_ps), _ps_ptr_array(c_ps), _ps_ptr_array(dz1_ps),
                                         _ps_ptr_array(dz2_ps), ptr(dx), nb, N, C, H, W, float(slope), stream()),
           "fdet_block_chain_bwd_ps")

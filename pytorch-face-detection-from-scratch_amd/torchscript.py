@@ -60,6 +60,9 @@ def _op_stack_forward(x: torch.Tensor, params: List[torch.Tensor], geo: List[int
     if len(params) != len(names):
         raise ValueError(f"fdet::stack_forward: expected {len(names)} parameter tensors, got {len(params)}")
     P = {n: p.detach() for n, p in zip(names, params)}
+    # the engine recognises "same weights" by (address, version): keep the tensors it packed from ALIVE, so that a module
+    # loaded later cannot be handed the same addresses by the caching allocator and be served the old packed panels
+    eng._src_refs = list(params)
     return eng.forward(x.detach(), P, None, save=False)[0]
 
 
@@ -79,6 +82,7 @@ def _op_mobilenet_forward(x: torch.Tensor, state: List[torch.Tensor], names: Lis
             _mb_engines.clear()
         eng = MobileNetStack()
         eng.pack({n: t.detach() for n, t in zip(names, state)})
+        eng._src_refs = list(state)                          # strong references: a cached key's addresses cannot be recycled
         _mb_engines[key] = eng
     return eng.forward(x.detach())
 
@@ -95,6 +99,7 @@ def _op_ssd_forward(x: torch.Tensor, params: List[torch.Tensor], filters: int, s
     names = ssd_param_names(filters)
     if len(params) != len(names):
         raise ValueError(f"fdet::ssd_forward: expected {len(names)} parameter tensors, got {len(params)}")
+    eng._src_refs = list(params)                             # as in _op_stack_forward
     return eng.forward(x.detach(), {n: p.detach() for n, p in zip(names, params)}, None, save=False)[0]
 
 

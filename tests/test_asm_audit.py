@@ -54,13 +54,15 @@ def test_no_instruction_touches_in_flight_asm_loads(src, tmp_path):
 # compiler-issued stores / prefetch loads.  tools/audit_vmcnt.py proves from the cross-compiled assembly that every K is
 # backed by a run of at least K vector-memory operations behind the nearest DMA piece and that no other run length can
 # reach the wait (a merged, dropped or duplicated store changes a run length).
-PS_CONV_TUS = list(range(8))           # PS_TU = 2 * mode + (WP == 64): FWD_FULL, DGRAD_ACT, FWD_POOL, DGRAD_ADDPOOL x {32, 64}
+PS_CONV_TUS = list(range(16))          # PS_TU = 8 * P16 + 2 * mode + (WP == 64): FWD_FULL, DGRAD_ACT, FWD_POOL, DGRAD_ADDPOOL x {32, 64} x precision
 VM_KERNELS = {
     # k_wgrad3x3_ps<WP, FL1 = true> (the default one-band flight) waits with vmcnt(0) only: listed so that a future counted
     # wait is audited.  FL1 = false counts asm DMA pieces themselves (volatile asm: the compiler cannot merge or drop them).
-    "fdet_wgrad3x3_ps.hip": ["_ZN12_GLOBAL__N_113k_wgrad3x3_psILi64ELb1E", "_ZN12_GLOBAL__N_113k_wgrad3x3_psILi32ELb1E",
-                             "_ZN12_GLOBAL__N_113k_wgrad3x3_psILi16ELb1E"],
-    "fdet_chain_x3.hip": ["_ZN12_GLOBAL__N_116k_block_chain_psILb0E", "_ZN12_GLOBAL__N_116k_block_chain_psILb1E",
+    "fdet_wgrad3x3_ps.hip": ["_ZN12_GLOBAL__N_113k_wgrad3x3_psILi64ELb1ELb0E", "_ZN12_GLOBAL__N_113k_wgrad3x3_psILi32ELb1ELb0E",
+                             "_ZN12_GLOBAL__N_113k_wgrad3x3_psILi16ELb1ELb0E", "_ZN12_GLOBAL__N_113k_wgrad3x3_psILi64ELb1ELb1E",
+                             "_ZN12_GLOBAL__N_113k_wgrad3x3_psILi32ELb1ELb1E", "_ZN12_GLOBAL__N_113k_wgrad3x3_psILi16ELb1ELb1E"],
+    "fdet_chain_x3.hip": ["_ZN12_GLOBAL__N_116k_block_chain_psILb0ELb0E", "_ZN12_GLOBAL__N_116k_block_chain_psILb1ELb0E",
+                          "_ZN12_GLOBAL__N_116k_block_chain_psILb0ELb1E", "_ZN12_GLOBAL__N_116k_block_chain_psILb1ELb1E",
                           "_ZN12_GLOBAL__N_116k_block_chain_x3ILb0E"],
 }
 
@@ -79,16 +81,21 @@ def test_hand_counted_vmcnt_waits_of_the_lds_dma_kernels(tmp_path):
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     jobs = [("fdet_conv3x3_ps.hip", str(tmp_path / f"ps{tu}.s"), [f"-DPS_TU={tu}"]) for tu in PS_CONV_TUS]
     jobs += [(src, str(tmp_path / (src + ".s")), []) for src in VM_KERNELS]
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         outs = list(ex.map(_compile_s, jobs))
-    todo = [("_ZN12_GLOBAL__N_112k_conv3x3_ps", o) for o in outs[:len(PS_CONV_TUS)]]
+    # The fused pooled forward (mode 2: TUs 4, 5, 12, 13) is checked with rule B only.  Its K counts the epilogue's STORES;
+    # between the DMA and the wait every path also carries the epilogue's >= 32 skip-tensor loads (uncounted slack: K <= 44
+    # <= 32 + stores), and hipcc compiles each `offset = valid ? address : out-of-range` store as TWO stores under
+    # complementary EXEC masks, each behind its own s_cbranch_execz -- at least one of the pair always issues, which can
+    # only add operations, but a walk that cannot pair the masks sees every subset as a path (rule A would flag those).
+    todo = [("_ZN12_GLOBAL__N_112k_conv3x3_ps", o, (tu & 7) // 2 != 2) for tu, o in zip(PS_CONV_TUS, outs[:len(PS_CONV_TUS)])]
     for src, o in zip(VM_KERNELS, outs[len(PS_CONV_TUS):]):
-        todo += [(k, o) for k in VM_KERNELS[src]]
+        todo += [(k, o, True) for k in VM_KERNELS[src]]
     n_waits = 0
-    for k, o in todo:
+    for k, o, rule_a in todo:
         res, ndma = mod.audit(k, o)
         assert ndma > 0, f"{k}: no LDS-DMA pieces found (kernel renamed?)"
-        bad = mod.check(res)
+        bad = mod.check(res, rule_a=rule_a)
         print(f"{k} ({os.path.basename(o)}): {ndma} DMA pieces, {len(res)} hand-counted waits: {sorted({K for _, K, _ in res})}")
         assert not bad, f"{k} ({os.path.basename(o)}): {bad[:3]}"
         n_waits += len(res)

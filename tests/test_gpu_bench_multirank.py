@@ -22,7 +22,7 @@ def _bench(args, extra_env=None):
         env.pop(k, None)
     env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args + ["--no-cpu-baseline", "--no-inference",
-                       "--no-configs", "--no-feed"], env=env, capture_output=True, text=True, timeout=900)
+                       "--no-configs", "--no-feed", "--no-p16"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                 # exactly ONE JSON line, from rank 0

@@ -1,0 +1,251 @@
+"""GPU tests of the `precision16` mode (round 4): the PS kernels with ONE bf16 MFMA pass on the hi planes -- bf16
+activations and weights, fp32 accumulation -- the arithmetic of the reference's `Trainer(precision=16)`
+(train_model.py:50) with bf16 as the 16-bit type.
+
+Kernel level: against torch CPU ops on operands rounded to bf16 the way the kernels see them (an activation is the hi
+plane of its PS tensor, a weight the hi half of its packed panel), so that the only differences left are fp32 summation
+order and ONE bf16 rounding of the stored result: tolerance 2^-8 of the value (+ 2e-5 of the tensor's scale).
+Model level: the fixture g17 = the reference PoolResnet(filters=64) train step under torch.autocast("cpu", bfloat16)
+(tools/make_goldens_r4.py).  Autocast rounds after every op (conv, LeakyReLU, dropout, add ...), the kernels once per
+stored tensor, so the two agree to a few bf16 ulps, not to the bit: tolerances are stated at each assertion."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import fdet_amd
+    from fdet_amd import hotpath, ps
+    return hotpath, ps
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def close_bf16(got, ref, what=""):
+    """`got` holds bf16-rounded values of (approximately) `ref`."""
+    got = got.cpu().double(); ref = ref.cpu().double()
+    scale = max(1.0, float(ref.abs().max()))
+    err = (got - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 2e-5 * scale
+    bad = err > bound
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} entries off, worst {float((err - bound).max()):.3e} over the bound"
+
+
+def close(a, b, tol=1e-4):
+    a = a.cpu().double(); b = b.cpu().double()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"max err {err} vs scale {scale}"
+
+
+def _pack(hp, w):
+    C = w.shape[0]
+    nf, nb = hp.packed_sizes(C, C)
+    wf = torch.empty(nf, device="cuda"); wb = torch.empty(nb, device="cuda")
+    hp.pack_conv3x3_weights(w.cuda(), wf, wb, x3=True)
+    return wf, wb
+
+
+def _hi_only(ps, x):
+    """PS tensor whose hi plane is bf16(x) and whose lo plane is zero (what a precision16 producer leaves)."""
+    return ps.PsTensor.from_f32(bf(x).cuda())
+
+
+P16_SHAPES = [(3, 64, 60, 60), (5, 64, 30, 30), (2, 64, 12, 56), (9, 64, 16, 30)]
+
+
+@pytest.mark.parametrize("shape", P16_SHAPES)
+def test_p16_conv_fwd_and_dgrad(env, shape):
+    hp, ps = env
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    wf, wb = _pack(hp, w)
+    xp = _hi_only(ps, x)
+    yp = ps.PsTensor(N, C, H, W, "cuda")
+    ps.conv3x3_ps_fwd(xp, wf, b.cuda(), yp, slope=0.2, p16=True)
+    z = F.leaky_relu(F.conv2d(bf(x).double(), bf(w).double(), b.double(), padding=1), 0.2)
+    y = yp.to_f32()
+    close_bf16(y, z, "forward")
+    assert torch.equal(y.cpu(), bf(y.cpu()))                 # only the hi plane was written: the values are bf16 numbers
+    # halos untouched
+    real = ps.PsTensor.from_f32(torch.full((N, C, H, W), 1.0 + 2.0 ** -9, device="cuda"))
+    outside = real.buf.view(torch.int16) == 0
+    assert int((yp.buf.view(torch.int16)[outside] != 0).sum()) == 0
+    # data gradient x LeakyReLU' of a saved activation (read from its hi plane)
+    dz = torch.randn(N, C, H, W, generator=g)
+    act = torch.randn(N, C, H, W, generator=g)
+    dzp = _hi_only(ps, dz); ap = _hi_only(ps, act)
+    dxp = ps.PsTensor(N, C, H, W, "cuda")
+    ps.conv3x3_ps_dgrad_act(dzp, wb, ap, dxp, slope=0.2, p16=True)
+    ref = F.conv_transpose2d(bf(dz).double(), bf(w).double(), padding=1) * torch.where(bf(act) > 0, 1.0, 0.2)
+    close_bf16(dxp.to_f32(), ref, "dgrad")
+
+
+@pytest.mark.parametrize("shape", P16_SHAPES + [(3, 64, 15, 15), (2, 64, 5, 31)])
+@pytest.mark.parametrize("L", [1, 2])
+def test_p16_wgrad(env, shape, L):
+    """fp32 weight / bias gradients from bf16 operands: no output rounding, so the usual 1e-4 of the tensor's scale."""
+    hp, ps = env
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(N * 77 + H + W + L)
+    xs = [torch.randn(N, C, H, W, generator=g) for _ in range(L)]
+    dzs = [torch.randn(N, C, H, W, generator=g) for _ in range(L)]
+    # hi AND lo planes filled (from_f32 of the unrounded tensors): the kernel must ignore the lo planes
+    xp = [ps.PsTensor.from_f32(x.cuda()) for x in xs]
+    zp = [ps.PsTensor.from_f32(z.cuda()) for z in dzs]
+    dW = [torch.full((C, C, 3, 3), float("nan"), device="cuda") for _ in range(L)]
+    db = [torch.full((C,), float("nan"), device="cuda") for _ in range(L)]
+    ws = torch.empty(ps.conv3x3_wgrad_ps_ws_bytes(L, N, C, H, W) // 4, device="cuda")
+    ps.conv3x3_wgrad_ps_batched(xp, zp, dW, db, ws, p16=True)
+    for l in range(L):
+        xr, zr = bf(xs[l]).double(), bf(dzs[l]).double()
+        close(dW[l], torch.nn.grad.conv2d_weight(xr, (C, C, 3, 3), zr, padding=1))
+        close(db[l], zr.sum(dim=(0, 2, 3)))
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 60, 60), (5, 64, 30, 30)])
+def test_p16_pooled_block(env, shape):
+    hp, ps = env
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(N * 31 + H + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    skip = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    scale = (torch.rand(N, C, generator=g) > 0.25).float() / 0.75
+    wf, wb = _pack(hp, w)
+    xp, sp = _hi_only(ps, x), _hi_only(ps, skip)
+    pool_ps = ps.PsTensor(N, C, H // 2, W // 2, "cuda")
+    pool_f = torch.full((N, C, H // 2, W // 2), float("nan"), device="cuda")
+    route = ps.route8_like(N, C, H, W, "cuda")
+    ps.conv3x3_ps_fwd_pool(xp, wf, b.cuda(), sp, scale.cuda(), pool_ps, pool_f, route, p16=True)
+    c = F.leaky_relu(F.conv2d(bf(x).double(), bf(w).double(), b.double(), padding=1), 0.2)
+    u = c * scale[:, :, None, None].double() + bf(skip).double()
+    ref = F.max_pool2d(u, 2)
+    close(pool_f, ref)                                        # the fp32 output of the fused tail: no rounding
+    close_bf16(pool_ps.to_f32(), ref, "pooled PS")
+    # backward piece: conv1's data gradient + the un-pooled skip gradient through the routing bytes the kernel wrote
+    rt = route.permute(0, 1, 4, 2, 3).reshape(N, C, H // 2, W // 2).cpu().int()
+    arg = (rt >> 4) & 3
+    dout = torch.randn(N, C, H // 2, W // 2, generator=g)
+    dz1 = torch.randn(N, C, H, W, generator=g)
+    dzp = _hi_only(ps, dz1)
+    dx = torch.full((N, C, H, W), float("nan"), device="cuda")
+    ps.conv3x3_ps_dgrad_unpool(dzp, wb, dout.cuda(), route, dx, p16=True)
+    un = torch.zeros(N, C, 4, H // 2, W // 2)
+    for k in range(4):
+        un[:, :, k] = torch.where(arg == k, dout, torch.zeros(()))
+    un = F.fold(un.reshape(N * C, 4, -1), (H, W), 2, stride=2).reshape(N, C, H, W)
+    close(dx, F.conv_transpose2d(bf(dz1).double(), bf(w).double(), padding=1) + un.double())
+
+
+@pytest.mark.parametrize("cfg", [(3, 15, 15, 3), (2, 10, 10, 2), (5, 15, 15, 8)])
+def test_p16_block_chain_forward(env, cfg):
+    """The LDS-resident chain in precision16: every conv input is the bf16 rounding of the previous result, the skip
+    connection stays fp32 in registers (as in the kernel), the chain output is fp32."""
+    hp, ps = env
+    N, H, W, nb = cfg
+    C = 64
+    g = torch.Generator().manual_seed(N * 100 + H + nb)
+    x = torch.randn(N, C, H, W, generator=g)
+    Ws = [(torch.randn(C, C, 3, 3, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1,
+           torch.randn(C, C, 3, 3, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1) for _ in range(nb)]
+    scales = [((torch.rand(N, C, generator=g) > 0.25).float() / 0.75) for _ in range(nb)]
+    h = bf(x).double()                                       # the fp32 skip value of block 0 = the input as stored (bf16)
+    for k in range(nb):
+        w1, b1, w2, b2 = Ws[k]
+        a = F.leaky_relu(F.conv2d(bf(h.float()).double(), bf(w1).double(), b1.double(), padding=1), 0.2)
+        c = F.leaky_relu(F.conv2d(bf(a.float()).double(), bf(w2).double(), b2.double(), padding=1), 0.2)
+        h = c * scales[k][:, :, None, None].double() + h
+    wf1, wb1, wf2, wb2 = [], [], [], []
+    for (w1, b1, w2, b2) in Ws:
+        f_, b_ = _pack(hp, w1); wf1.append(f_); wb1.append(b_)
+        f_, b_ = _pack(hp, w2); wf2.append(f_); wb2.append(b_)
+    out = torch.full((N, C, H, W), float("nan"), device="cuda")
+    a_l = [ps.PsTensor(N, C, H, W, "cuda") for _ in range(nb)]
+    c_l = [ps.PsTensor(N, C, H, W, "cuda") for _ in range(nb)]
+    o_l = [ps.PsTensor(N, C, H, W, "cuda") for _ in range(nb - 1)]
+    ps.block_chain_fwd_ps(_hi_only(ps, x), wf1, [w[1].cuda() for w in Ws], wf2, [w[3].cuda() for w in Ws],
+                          [s.cuda() for s in scales], a_l, c_l, o_l, out, slope=0.2, p16=True)
+    # a bf16 rounding that falls the other way on a near-tie moves a later activation by one bf16 ulp (2^-8 = 3.9e-3 of
+    # its value); through up to 16 layers of 576-term sums the output stays within 1e-2 of its scale (measured: 3.3e-3 at
+    # 8 blocks, < 2e-3 at 2 and 3)
+    close(out, h, 1e-2)
+    for t in a_l + o_l:
+        v = t.to_f32().cpu()
+        assert torch.equal(v, bf(v))                         # hi planes only
+
+
+def _redraw_u8(B, size, seed, checksum):
+    x_u8 = torch.randint(0, 256, (B, 3, size, size), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
+    assert int(x_u8.long().sum()) == int(checksum)
+    return x_u8
+
+
+def test_p16_train_step_vs_reference_autocast_fixture(golden):
+    """g17: the reference PoolResnet(filters=64), one train step at B=2 under torch.autocast("cpu", bfloat16).  The engine in
+    precision16 on the same inputs, parameters (by seed) and dropout masks: y within 2e-2 absolute (sigmoid outputs),
+    loss within 2 %, every gradient tensor's norm within 5 % and its direction (cosine on the fixture's sample) >= 0.99."""
+    import fdet_amd  # noqa: F401
+    from fdet_amd.models import ModelMeta
+    from fdet_amd.models.PoolResnet import PoolResnet
+    g = golden("g17_poolresnet_F64_ac")
+    torch.manual_seed(int(g["param_seed"]))
+    model = PoolResnet(filters=64, input_shape=(3, 480, 480), num_of_patches=10, num_of_residual_blocks=10).cuda().train()
+    eng = model.engine
+    eng.set_precision("bf16")
+    assert eng.p16 and eng.ps
+    mm = ModelMeta(model=model, lr=1e-4)
+    mm.configure_optimizers()
+    x_u8 = _redraw_u8(2, 480, int(g["x_seed"]), g["x_sum"])
+    model.set_dropout_masks({k[len("mask/"):]: v for k, v in g.items() if k.startswith("mask/")})
+    lsum, y_hat, _ = mm.fused_train_step((x_u8.float() / 255.0).cuda(), g["y"].cuda())
+    assert float((y_hat.cpu() - g["y_train"]).abs().max()) <= 2e-2
+    assert abs(float(lsum) - float(g["loss"])) <= 2e-2 * float(g["loss"])
+    sp = mm.opt.space
+    names, _ = model.named_stack_params()
+    for i, n in enumerate(names):
+        got = sp.view(sp.grad, i).detach().cpu().double().reshape(-1)
+        ref = g["grad/" + n].double()
+        idx = g["idx/" + n].long()
+        assert abs(float(got.norm()) - float(g["grad_norm"][i])) <= 5e-2 * float(g["grad_norm"][i]), n
+        cos = float((got[idx] * ref).sum() / (got[idx].norm() * ref.norm()).clamp_min(1e-30))
+        assert cos >= 0.99, (n, cos)
+
+
+def test_p16_equals_fp32_grade_path_within_bf16(golden):
+    """The same step in the default bf16x3 arithmetic and in precision16: outputs within 2e-2, loss within 2 % -- the
+    cost of the 16-bit mode measured against the engine's own fp32-grade path (not absorbed into a tolerance elsewhere)."""
+    import fdet_amd  # noqa: F401
+    import oracle as O
+    from fdet_amd.models import ModelMeta
+    from fdet_amd.models.PoolResnet import PoolResnet
+    spec = O.poolresnet_spec(64, (3, 480, 480), 10)
+    P = O.init_params(spec, seed=4)
+    B = 3
+    x = torch.rand(B, 3, 480, 480, generator=torch.Generator().manual_seed(8)).cuda()
+    y = torch.stack([O.encode_targets(b, (480, 480), 10) for b in O.synthetic_boxes(B, 480, seed=6)]).cuda()
+    masks = O.make_dropout_masks(spec, B, seed=5)
+    res = {}
+    for mode in ("bf16x3", "bf16"):
+        model = PoolResnet(filters=64, input_shape=(3, 480, 480), num_of_patches=10)
+        model.load_state_dict({k: v.clone() for k, v in P.items()})
+        model = model.cuda().train()
+        model.engine.set_precision(mode)
+        mm = ModelMeta(model=model, lr=1e-4); mm.configure_optimizers()
+        model.set_dropout_masks(masks)
+        lsum, y_hat, _ = mm.fused_train_step(x, y)
+        res[mode] = (float(lsum), y_hat.clone(), mm.opt.space.grad.clone())
+    (la, ya, ga), (lb, yb, gb) = res["bf16x3"], res["bf16"]
+    assert abs(la - lb) <= 2e-2 * abs(la), (la, lb)
+    assert float((ya - yb).abs().max()) <= 2e-2
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert cos >= 0.995, cos

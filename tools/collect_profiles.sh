@@ -7,8 +7,8 @@ TAG=${1:-x}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-inference --no-configs --no-feed"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-inference --no-configs --no-feed > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-inference --no-configs --no-feed --no-p16"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-inference --no-configs --no-feed --no-p16 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -o f -- $B > /dev/null 2> $OUT/f.err
 echo "fetch done"
