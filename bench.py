@@ -41,13 +41,13 @@ FWD_MB_PER_IMAGE_F64 = 11.81
 FWD_GFLOP_PER_IMAGE_F64 = 1.0695
 # timer groups that are launches of ONE kernel symbol (rocprofv3 --stats adds them up under that name)
 SYMBOL_OF = {   # timer group -> kernel symbol (template instantiation) it launches on the default path; groups that share a symbol merge
-    "chain_fwd@15x15": "k_block_chain_ps<false>@15x15", "chain_bwd@15x15": "k_block_chain_ps<true>@15x15",
-    "conv3x3_wgrad@60x60": "k_wgrad3x3_ps<64,true>@60x60", "conv3x3_wgrad@30x30": "k_wgrad3x3_ps<32,true>@30x30",
-    "conv3x3_wgrad@15x15": "k_wgrad3x3_ps<16,true>@15x15",
-    "conv3x3_fwd@60x60": "k_conv3x3_ps<FWD_FULL,64>@60x60", "conv3x3_fwd@30x30": "k_conv3x3_ps<FWD_FULL,32>@30x30",
-    "conv3x3_fwd_pool@60x60": "k_conv3x3_ps<FWD_POOL,64>@60x60", "conv3x3_fwd_pool@30x30": "k_conv3x3_ps<FWD_POOL,32>@30x30",
-    "conv3x3_dgrad@60x60": "k_conv3x3_ps<DGRAD_ACT,64>@60x60", "conv3x3_dgrad@30x30": "k_conv3x3_ps<DGRAD_ACT,32>@30x30",
-    "conv3x3_dgrad_unpool@60x60": "k_conv3x3_ps<DGRAD_ADDPOOL,64>@60x60", "conv3x3_dgrad_unpool@30x30": "k_conv3x3_ps<DGRAD_ADDPOOL,32>@30x30",
+    "chain_fwd@15x15": "k_block_chain_ps<false,false>@15x15", "chain_bwd@15x15": "k_block_chain_ps<true,false>@15x15",
+    "conv3x3_wgrad@60x60": "k_wgrad3x3_ps<64,true,false>@60x60", "conv3x3_wgrad@30x30": "k_wgrad3x3_ps<32,true,false>@30x30",
+    "conv3x3_wgrad@15x15": "k_wgrad3x3_ps<16,true,false>@15x15",
+    "conv3x3_fwd@60x60": "k_conv3x3_ps<FWD_FULL,64,false>@60x60", "conv3x3_fwd@30x30": "k_conv3x3_ps<FWD_FULL,32,false>@30x30",
+    "conv3x3_fwd_pool@60x60": "k_conv3x3_ps<FWD_POOL,64,false>@60x60", "conv3x3_fwd_pool@30x30": "k_conv3x3_ps<FWD_POOL,32,false>@30x30",
+    "conv3x3_dgrad@60x60": "k_conv3x3_ps<DGRAD_ACT,64,false>@60x60", "conv3x3_dgrad@30x30": "k_conv3x3_ps<DGRAD_ACT,32,false>@30x30",
+    "conv3x3_dgrad_unpool@60x60": "k_conv3x3_ps<DGRAD_ADDPOOL,64,false>@60x60", "conv3x3_dgrad_unpool@30x30": "k_conv3x3_ps<DGRAD_ADDPOOL,32,false>@30x30",
 }
 
 
@@ -388,6 +388,31 @@ def extra_configs(device):
         del model, mm, x, y
     except Exception as e:                                   # noqa: BLE001 (a leg must not take the headline line down)
         out["config3_1gpu"] = {"error": repr(e)[:300]}
+    # PoolResnet "large" (filters 128): what the reference's train_model.py:17,27-31 actually trains.  Its layers run on the
+    # round-2 fp32-I/O bf16x3 kernels (the PS machinery is 64-channel only): reported so that the gap is on record.
+    try:
+        from fdet_amd.models.PoolResnet import PoolResnet
+        from fdet_amd.convstack import KernelTimer
+        B, size, S = 256, 480, 10
+        torch.manual_seed(0)
+        model = PoolResnet(filters=128, input_shape=(3, size, size), num_of_patches=S, num_of_residual_blocks=10).to(device).train()
+        mm = ModelMeta(model=model, lr=1e-4); mm.configure_optimizers()
+        x = torch.rand(B, 3, size, size, generator=g).to(device)
+        y = hp.encode_targets(synthetic_boxes(B, size, seed=4), (size, size), S, device=device)
+        dt, r = _time_steps(lambda: mm.fused_train_step(x, y), 2, 5)
+        timer = KernelTimer(); model.engine.timer = timer
+        mm.fused_train_step(x, y)
+        model.engine.timer = None
+        per = timer.summary()
+        out["poolresnet_large_F128_1gpu"] = {
+            "workload": "PoolResnet-large (filters 128, 10 blocks, S=10) 3x480x480, bs 256, fwd + YoloLoss + bwd + Adam",
+            "ms_per_step": round(dt * 1e3, 3), "imgs_per_s": round(B / dt, 1), "finite_loss": bool(torch.isfinite(r[0]).all()),
+            "ps_path": bool(model.engine.ps), **floors(B * 11.7145, B * 48.27, 3.0, dt * 1e3),
+            "kernels_ms_per_step": {k: round(tot, 4) for k, (n_l, tot, fl, nb) in sorted(per.items(), key=lambda kv: -kv[1][1])[:8]}}
+        del model, mm, x, y
+        torch.cuda.empty_cache()
+    except Exception as e:                                   # noqa: BLE001
+        out["poolresnet_large_F128_1gpu"] = {"error": repr(e)[:300]}
     # config 4: SSD filters 16, 4774 priors, hard-negative ratio 10, 64 images per GPU (global 512 on 8)
     try:
         B, size = 64, 480
@@ -397,10 +422,21 @@ def extra_configs(device):
         x = torch.rand(B, 3, size, size, generator=g).to(device)
         y = hp.ssd_encode_targets(synthetic_boxes(B, size, seed=2), (size, size), device=device)
         dt, r = _time_steps(lambda: mm.fused_train_step(x, y), 2, 5)
+        k4 = None
+        try:                                                 # per-kernel table of one step (HIP events on the launch stream)
+            from fdet_amd.convstack import KernelTimer
+            eng4 = model.engine
+            timer4 = KernelTimer(); eng4.timer = timer4
+            mm.fused_train_step(x, y)
+            eng4.timer = None
+            k4 = {k: round(tot, 4) for k, (n_l, tot, fl, nb) in sorted(timer4.summary().items(), key=lambda kv: -kv[1][1])[:10]}
+        except Exception:                                    # noqa: BLE001 (the SSD engine may not carry a timer)
+            k4 = None
         # forward 7.18 GMAC per image; backward = data + weight gradients of the same layers
         out["config4_1gpu"] = {"workload": "SSD filters 16, 3x480x480, 4774 priors, bs 64 per GPU, fwd + ssd_loss + bwd + Adam",
                                "ms_per_step": round(dt * 1e3, 3), "imgs_per_s": round(B / dt, 1),
-                               "finite_loss": bool(torch.isfinite(r[0]).all()), **floors(B * 3 * 14.36, 0.0, 3.0, dt * 1e3)}
+                               "finite_loss": bool(torch.isfinite(r[0]).all()), **floors(B * 3 * 14.36, 0.0, 3.0, dt * 1e3),
+                               "kernels_ms_per_step": k4}
         del model, mm, x, y
     except Exception as e:                                   # noqa: BLE001
         out["config4_1gpu"] = {"error": repr(e)[:300]}
@@ -465,7 +501,7 @@ def pmc_traffic_for(kernel_group: str, B: int, F_: int):
     """HBM bytes per launch of a kernel group from the committed rocprofv3 PMC passes (profiles/*pmc_traffic*.json
     written by tools/pmc_traffic.py with the source hash of the build it profiled) -- null when the sources have
     changed since, or for another batch / width."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     try:
         tj = json.load(open(path))
         if tj.get("csrc_sha256") != kernel_source_hash() or tj.get("batch") != B or tj.get("filters") != F_:

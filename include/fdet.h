@@ -459,6 +459,12 @@ int fdet_conv3x3_ps_fwd_pool_p16(const void* x_ps, const void* wpk, const float*
 int fdet_conv3x3_ps_dgrad_unpool_p16(const void* dz_ps, const void* wpk, const float* dout_pooled,
                                      const unsigned char* route8, float* dx, int N, int Cin, int Cout, int H, int W,
                                      float slope, void* stream);
+int fdet_pool_route_bwd_ps_p16(const float* dout_pooled, const unsigned char* route8, const float* drop_scale,
+                               void* dz2_ps, int N, int C, int H, int W, float slope, void* stream);
+int fdet_stem_fwd_ps_p16(const float* x, const float* w, const float* bias, void* y_ps, int N, int Cin, int F, int H,
+                         int W, int k, int stride, int pad, void* stream);
+int fdet_stem_wgrad_bf16(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,
+                         int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream);
 int fdet_conv3x3_wgrad_ps_batched_p16(const void* const* h_x, const void* const* h_dz, float* const* h_dW,
                                       float* const* h_db, int L, int N, int C, int H, int W, void* ws,
                                       size_t ws_bytes, void* stream);

@@ -310,7 +310,7 @@ class ConvStack:
         with self._t("stem_fwd", N, self.h0, stem_flops, stem_bytes):
             if self._ps_block(0) and stem_x3:
                 h, h_ps = None, self._ps_take(scope, N, F_, self.h0, self.h0, dev)
-                psm.stem_fwd_ps(x, P["conv1.weight"], P["conv1.bias"], h_ps, g.stem_k, g.stem_s, g.stem_p)
+                psm.stem_fwd_ps(x, P["conv1.weight"], P["conv1.bias"], h_ps, g.stem_k, g.stem_s, g.stem_p, p16=self.p16)
             else:
                 hp.stem_fwd(x, P["conv1.weight"], P["conv1.bias"], h, ws, g.stem_k, g.stem_s, g.stem_p, x3=stem_x3)
         saved = {"x": x, "blocks": [], "masks": masks, "ps_scope": scope} if save else None
@@ -597,7 +597,7 @@ class ConvStack:
                 fl = self._conv_flops(N, hk)
                 dz2 = self._ps_take(scope, N, F_, hk, hk, dev)
                 with self._t("pool_route_bwd", N, hk, 0.0, self._act_bytes(N, hk, 1 + 0.25 + 1 / 16)):
-                    psm.pool_route_bwd_ps(dout, c, sc, dz2, self.slope)
+                    psm.pool_route_bwd_ps(dout, c, sc, dz2, self.slope, p16=self.p16)
                 dz1 = self._ps_take(scope, N, F_, hk, hk, dev)
                 with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
                     psm.conv3x3_ps_dgrad_act(dz2, self._wpk[name + ".conv2.b"], a, dz1, self.slope, p16=self.p16)
@@ -661,8 +661,9 @@ class ConvStack:
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
         with self._t("stem_wgrad", N, self.h0, stem_flops, 4.0 * N * (g.in_ch * g.H * g.W + F_ * self.h0 * self.h0)):
-            hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p,
-                          x3=self.x3 and g.W % 16 == 0 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p))
+            stem_x3 = self.x3 and g.W % 16 == 0 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)
+            hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p, x3=stem_x3,
+                          p16=self.p16 and stem_x3 and 48 < self.h0 <= 60)
         join()
         if saved.get("ps_scope") is not None:
             saved["ps_scope"].release()                    # the saved PS activations / gradients are dead: back to the pool

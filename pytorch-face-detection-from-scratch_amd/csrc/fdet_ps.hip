@@ -47,6 +47,7 @@ k_ps_to_f32(const ps_bf16x8* __restrict__ ps, float* __restrict__ x, PsGeo g, in
 // backward of the fused pooled-block tail into a PS tensor: dz2 = unpool(dout) * drop_scale * lrelu'(c) from the pooled
 // gradient (fp32 NCHW) and the channel-innermost routing bytes (route8 [N][C/8][Hp][Wp][8]) of the forward pass.
 // One thread per (image, channel group, window): 8 channels x 4 positions = four hi and four lo units.
+template <bool P16>
 __global__ void __launch_bounds__(256)
 k_pool_route_bwd_ps(const float* __restrict__ dout, const unsigned char* __restrict__ route8, const float* __restrict__ scale,
                     ps_bf16x8* __restrict__ dz, PsGeo g, int Hp, int Wp, float slope, int total) {
@@ -74,26 +75,41 @@ k_pool_route_bwd_ps(const float* __restrict__ dout, const unsigned char* __restr
       const float f = ((int)((mk[j] >> 4) & 3) == k) ? gv[j] * (((mk[j] >> k) & 1) ? 1.f : slope) : 0.f;
       const __bf16 h = (__bf16)f;
       hi[j] = h;
-      lo[j] = (__bf16)(f - (float)h);
+      if (!P16) lo[j] = (__bf16)(f - (float)h);
     }
     const size_t u = (size_t)n * g.img + (size_t)(gr * g.HP + 2 * yp + (k >> 1)) * g.WP + 2 * xp + (k & 1) + 1;
     dz[u] = hi;
-    dz[u + g.plane] = lo;
+    if (!P16) dz[u + g.plane] = lo;                        // precision16: the hi plane only
   }
 }
 
 }  // namespace
 
-extern "C" int fdet_pool_route_bwd_ps(const float* dout_pooled, const unsigned char* route8, const float* drop_scale,
-                                      void* dz2_ps, int N, int C, int H, int W, float slope, void* stream) {
+namespace {
+int pool_route_bwd_ps_run(const float* dout_pooled, const unsigned char* route8, const float* drop_scale,
+                          void* dz2_ps, int N, int C, int H, int W, float slope, void* stream, bool p16) {
   PsGeo g;
   FDET_REQUIRE(dout_pooled && route8 && dz2_ps && !(H & 1) && !(W & 1) && ps_geo(N, C, H, W, g),
                "pool_route_bwd_ps: unsupported shape N=%d C=%d H=%d W=%d (even H, W; C %% 8 == 0; W <= 62)", N, C, H, W);
   const long long total = (long long)N * g.C8 * (H / 2) * (W / 2);
   FDET_REQUIRE(total < (1ll << 31), "pool_route_bwd_ps: tensor too large");
-  hipLaunchKernelGGL(k_pool_route_bwd_ps, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     dout_pooled, route8, drop_scale, reinterpret_cast<ps_bf16x8*>(dz2_ps), g, H / 2, W / 2, slope, (int)total);
+  if (p16)
+    hipLaunchKernelGGL(k_pool_route_bwd_ps<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dout_pooled, route8, drop_scale, reinterpret_cast<ps_bf16x8*>(dz2_ps), g, H / 2, W / 2, slope, (int)total);
+  else
+    hipLaunchKernelGGL(k_pool_route_bwd_ps<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dout_pooled, route8, drop_scale, reinterpret_cast<ps_bf16x8*>(dz2_ps), g, H / 2, W / 2, slope, (int)total);
   return check_launch("fdet_pool_route_bwd_ps");
+}
+}  // namespace
+
+extern "C" int fdet_pool_route_bwd_ps(const float* dout_pooled, const unsigned char* route8, const float* drop_scale,
+                                      void* dz2_ps, int N, int C, int H, int W, float slope, void* stream) {
+  return pool_route_bwd_ps_run(dout_pooled, route8, drop_scale, dz2_ps, N, C, H, W, slope, stream, false);
+}
+extern "C" int fdet_pool_route_bwd_ps_p16(const float* dout_pooled, const unsigned char* route8, const float* drop_scale,
+                                          void* dz2_ps, int N, int C, int H, int W, float slope, void* stream) {
+  return pool_route_bwd_ps_run(dout_pooled, route8, drop_scale, dz2_ps, N, C, H, W, slope, stream, true);
 }
 
 extern "C" size_t fdet_ps_bytes(int N, int C, int H, int W) {

@@ -18,8 +18,8 @@ size_t stem_mfma_ws_floats(int N, int F, int H, int W);
 int stem_mfma_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W, hipStream_t st);
 int stem_mfma_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st);
 int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W, hipStream_t st);   // fdet_stem_x3.hip
-int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st);
-int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st);
+int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16);
+int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st, bool p16);
 }
 
 namespace {
@@ -369,7 +369,17 @@ extern "C" int fdet_stem_fwd_ps(const float* x, const float* w, const float* bia
   FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad),
                "stem_fwd_ps: only the PoolResnet stem (3ch k10 s8 p2, W%%4==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
                Cin, k, stride, pad, W);
-  return stem_x3_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream);
+  return stem_x3_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, false);
+}
+
+// precision16: one MFMA pass on bf16(x) x bf16(w), hi plane of the PS output only (see fdet_conv3x3_ps_fwd_p16)
+extern "C" int fdet_stem_fwd_ps_p16(const float* x, const float* w, const float* bias, void* y_ps, int N, int Cin, int F, int H,
+                                    int W, int k, int stride, int pad, void* stream) {
+  FDET_REQUIRE(x && w && bias && y_ps && N > 0 && F == 64, "stem_fwd_ps_p16: bad arguments (F must be 64)");
+  FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad),
+               "stem_fwd_ps_p16: only the PoolResnet stem (3ch k10 s8 p2, W%%4==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
+               Cin, k, stride, pad, W);
+  return stem_x3_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, true);
 }
 
 extern "C" int fdet_stem_wgrad_bf16x3(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,
@@ -379,7 +389,18 @@ extern "C" int fdet_stem_wgrad_bf16x3(const float* x, const float* dy, float* dW
                "stem_wgrad_bf16x3: only the PoolResnet stem (3ch k10 s8 p2, W%%16==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
                Cin, k, stride, pad, W);
   if (ws_bytes < stem_mfma_ws_floats(N, F, H, W) * 4) return fail(FDET_EWORKSPACE, "stem_wgrad_bf16x3: workspace too small");
-  return stem_x3_wgrad(x, dy, dW, db, (float*)ws, N, F, H, W, (hipStream_t)stream);
+  return stem_x3_wgrad(x, dy, dW, db, (float*)ws, N, F, H, W, (hipStream_t)stream, false);
+}
+
+// precision16: one MFMA pass on bf16(dy) x bf16(x), fp32 accumulation; same workspace as fdet_stem_wgrad_bf16x3
+extern "C" int fdet_stem_wgrad_bf16(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,
+                                    int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream) {
+  FDET_REQUIRE(x && dy && dW && db && ws && N > 0 && F > 0, "stem_wgrad_bf16: bad arguments");
+  FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad) && W % 16 == 0,
+               "stem_wgrad_bf16: only the PoolResnet stem (3ch k10 s8 p2, W%%16==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
+               Cin, k, stride, pad, W);
+  if (ws_bytes < stem_mfma_ws_floats(N, F, H, W) * 4) return fail(FDET_EWORKSPACE, "stem_wgrad_bf16: workspace too small");
+  return stem_x3_wgrad(x, dy, dW, db, (float*)ws, N, F, H, W, (hipStream_t)stream, true);
 }
 
 extern "C" int fdet_stem_wgrad(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,

@@ -175,10 +175,19 @@ __device__ __forceinline__ void sx_split_pair(float f0, float f1, unsigned& hi, 
   lo = __builtin_bit_cast(unsigned, lb);
 }
 
-template <bool PSO>
+__device__ __forceinline__ unsigned sx_hi_pair(float f0, float f1) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t h = {(__bf16)f0, (__bf16)f1};
+  return __builtin_bit_cast(unsigned, h);
+}
+
+// P16 (precision16, PS output only): one MFMA pass on bf16(x) x bf16(w); the lo halves are neither computed nor staged and
+// only the hi plane of the output is written.
+template <bool PSO, bool P16 = false>
 __global__ void __launch_bounds__(256, 1)
 k_stem_fwd_x3_pipe(const StemX3Args a) {
-  constexpr int NST = PSO ? 4 : 16;                    // output stores per row (they sit in the memory queue of the counted waits)
+  static_assert(PSO || !P16, "precision16 stem: PS output only");
+  constexpr int NST = PSO ? (P16 ? 2 : 4) : 16;        // output stores per row (they sit in the memory queue of the counted waits)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = NROW * RL * 2;                   // bf16 elements per tile: hi rows, then lo rows
   __bf16* const base = reinterpret_cast<__bf16*>(smem);
@@ -203,7 +212,7 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
       const float f = (co < a.F && kx >= 0 && kx < KS) ? a.w[((size_t)co * CIN * KS + rr) * KS + kx] : 0.f;
       const __bf16 h = (__bf16)f;
       ah[rr][j] = h;
-      al[rr][j] = (__bf16)(f - (float)h);
+      if (!P16) al[rr][j] = (__bf16)(f - (float)h);
     }
   }
   const unsigned long long pa = (unsigned long long)a.x;
@@ -232,10 +241,15 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
   {                                                                                             \
     __bf16* d_ = base + (TB) * TILE + (2 * (SL) + rsub) * RL + 4 + 4 * j4;                      \
     unsigned h0, l0, h1, l1;                                                                    \
-    sx_split_pair(p##S[SL][0], p##S[SL][1], h0, l0); sx_split_pair(p##S[SL][2], p##S[SL][3], h1, l1); \
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));                               \
-    *reinterpret_cast<u32x2_t*>(d_) = u32x2_t{h0, h1};                                          \
-    *reinterpret_cast<u32x2_t*>(d_ + NROW * RL) = u32x2_t{l0, l1};                              \
+    if (P16) {                                                                                  \
+      h0 = sx_hi_pair(p##S[SL][0], p##S[SL][1]); h1 = sx_hi_pair(p##S[SL][2], p##S[SL][3]);     \
+      *reinterpret_cast<u32x2_t*>(d_) = u32x2_t{h0, h1};                                        \
+    } else {                                                                                    \
+      sx_split_pair(p##S[SL][0], p##S[SL][1], h0, l0); sx_split_pair(p##S[SL][2], p##S[SL][3], h1, l1); \
+      *reinterpret_cast<u32x2_t*>(d_) = u32x2_t{h0, h1};                                        \
+      *reinterpret_cast<u32x2_t*>(d_ + NROW * RL) = u32x2_t{l0, l1};                            \
+    }                                                                                           \
   }
   const int bpw = (a.nrows + (int)gridDim.x - 1) / (int)gridDim.x;
   int row = blockIdx.x * bpw;
@@ -270,14 +284,16 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
     f32x16 acc;                                                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.f;                                \
     bf16x8 bh[2], bl[2];                                                                        \
-    bh[0] = Bh[0]; bl[0] = Bl[0];                                                               \
+    bh[0] = Bh[0]; if (!P16) bl[0] = Bl[0];                                                     \
     SXP_WAIT(S, NST + NSLOT)                                                                    \
     sx_static_for<NROW>(SX_LAMBDA(rr_) {                                                        \
       constexpr int rr = rr_;                                                                   \
       constexpr int cur = rr & 1, nxt = cur ^ 1;                                                \
-      if (rr + 1 < NROW) { bh[nxt] = Bh[(rr + 1) * RC]; bl[nxt] = Bl[(rr + 1) * RC]; }          \
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bl[cur], acc, 0, 0, 0);             \
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bh[cur], acc, 0, 0, 0);             \
+      if (rr + 1 < NROW) { bh[nxt] = Bh[(rr + 1) * RC]; if (!P16) bl[nxt] = Bl[(rr + 1) * RC]; } \
+      if (!P16) {                                                                               \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bl[cur], acc, 0, 0, 0);           \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bh[cur], acc, 0, 0, 0);           \
+      }                                                                                         \
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bh[cur], acc, 0, 0, 0);             \
       if constexpr (rr < NSLOT) SXP_JOB(S, rr, S)                                               \
       if constexpr (rr >= 4 && rr - 4 < NSLOT) SXP_LOAD1(S, rr - 4, n3_, oy3_)                  \
@@ -293,19 +309,20 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
           zb[i] = acc[8 * gp + 4 + i] + sbias[m * 32 + 16 * gp + 8 + 4 * half + i];             \
         }                                                                                       \
         unsigned ha[2], la[2], hb[2], lb[2];                                                    \
-        ps_split4(za, ha, la);                                                                  \
-        ps_split4(zb, hb, lb);                                                                  \
+        if (P16) { ps_hi4(za, ha); ps_hi4(zb, hb); } else { ps_split4(za, ha, la); ps_split4(zb, hb, lb); } \
         _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                         \
           auto r1 = __builtin_amdgcn_permlane32_swap(ha[k], hb[k], false, false);               \
           ha[k] = r1[0]; hb[k] = r1[1];                                                         \
-          auto r2 = __builtin_amdgcn_permlane32_swap(la[k], lb[k], false, false);               \
-          la[k] = r2[0]; lb[k] = r2[1];                                                         \
+          if (!P16) {                                                                           \
+            auto r2 = __builtin_amdgcn_permlane32_swap(la[k], lb[k], false, false);             \
+            la[k] = r2[0]; lb[k] = r2[1];                                                       \
+          }                                                                                     \
         }                                                                                       \
         const int G = 4 * m + 2 * gp + half;                                                    \
         const unsigned off = (ox < a.Wo && row < last) ? (unsigned)(n * a.ps_img + (G * a.ps_hp + oy) * a.ps_wp + ox + 1) * 16u : 0x80000000u; \
         typedef unsigned sx_u32x4 __attribute__((ext_vector_type(4)));                          \
         __builtin_amdgcn_raw_buffer_store_b128(sx_u32x4{ha[0], ha[1], hb[0], hb[1]}, ry, off, 0, 0); \
-        __builtin_amdgcn_raw_buffer_store_b128(sx_u32x4{la[0], la[1], lb[0], lb[1]}, ry, off, a.ps_plane * 16, 0); \
+        if (!P16) __builtin_amdgcn_raw_buffer_store_b128(sx_u32x4{la[0], la[1], lb[0], lb[1]}, ry, off, a.ps_plane * 16, 0); \
       }                                                                                         \
     } else {                                                                                    \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                            \
@@ -526,6 +543,8 @@ k_stem_wgrad_x3(const StemWgX3Args a) {
 constexpr int PCP = 9, PEP = PCP * 8;      // plane pitch of the pipelined kernel
 constexpr int TILEP = NPLANE * PEP * 2;    // bf16 elements per plane tile (hi planes, then lo planes)
 
+// P16 (precision16): one MFMA pass on bf16(dy) x bf16(x); the lo planes are neither computed nor staged.
+template <bool P16>
 __global__ void __launch_bounds__(256, 1)
 k_stem_wgrad_x3_pipe(const StemWgX3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -609,19 +628,29 @@ k_stem_wgrad_x3_pipe(const StemWgX3Args a) {
 #define SWP_JOB(S, SL, I, TB)                                                                     \
   {                                                                                               \
     unsigned hi_, lo_;                                                                            \
-    sx_split_pair(px##S[SL][(I) >> 2][(I) & 3], px##S[SL][2 + ((I) >> 2)][(I) & 3], hi_, lo_);    \
     __bf16* d_ = (xw_off[SL] >= 0 ? base + (TB) * TILEP + xw_off[SL] : junk) + (I) * PEP;         \
-    *reinterpret_cast<unsigned*>(d_) = hi_;                                                       \
-    *reinterpret_cast<unsigned*>(d_ + (xw_off[SL] >= 0 ? NPLANE * PEP : 0)) = lo_;                \
+    if (P16) {                                                                                    \
+      hi_ = sx_hi_pair(px##S[SL][(I) >> 2][(I) & 3], px##S[SL][2 + ((I) >> 2)][(I) & 3]);         \
+      *reinterpret_cast<unsigned*>(d_) = hi_;                                                     \
+    } else {                                                                                      \
+      sx_split_pair(px##S[SL][(I) >> 2][(I) & 3], px##S[SL][2 + ((I) >> 2)][(I) & 3], hi_, lo_);  \
+      *reinterpret_cast<unsigned*>(d_) = hi_;                                                     \
+      *reinterpret_cast<unsigned*>(d_ + (xw_off[SL] >= 0 ? NPLANE * PEP : 0)) = lo_;              \
+    }                                                                                             \
   }
   // dy tile (lanes past the row hold zeros and write them into the row's zero pad)
 #define SWP_STAGE_D()                                                                             \
   sx_static_for<4>(SX_LAMBDA(s_) {                                                                \
     unsigned h0, l0, h1, l1;                                                                      \
-    sx_split_pair(pd[s_][0], pd[s_][1], h0, l0); sx_split_pair(pd[s_][2], pd[s_][3], h1, l1);     \
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));                                 \
-    *reinterpret_cast<u32x2_t*>(Dh + dw_off[s_]) = u32x2_t{h0, h1};                               \
-    *reinterpret_cast<u32x2_t*>(Dl + dw_off[s_]) = u32x2_t{l0, l1};                               \
+    if (P16) {                                                                                    \
+      h0 = sx_hi_pair(pd[s_][0], pd[s_][1]); h1 = sx_hi_pair(pd[s_][2], pd[s_][3]);               \
+      *reinterpret_cast<u32x2_t*>(Dh + dw_off[s_]) = u32x2_t{h0, h1};                             \
+    } else {                                                                                      \
+      sx_split_pair(pd[s_][0], pd[s_][1], h0, l0); sx_split_pair(pd[s_][2], pd[s_][3], h1, l1);   \
+      *reinterpret_cast<u32x2_t*>(Dh + dw_off[s_]) = u32x2_t{h0, h1};                             \
+      *reinterpret_cast<u32x2_t*>(Dl + dw_off[s_]) = u32x2_t{l0, l1};                             \
+    }                                                                                             \
     bpart[s_] += (pd[s_][0] + pd[s_][1]) + (pd[s_][2] + pd[s_][3]);                               \
   });
   {
@@ -651,8 +680,8 @@ k_stem_wgrad_x3_pipe(const StemWgX3Args a) {
     const bf16x8* Bh = reinterpret_cast<const bf16x8*>(base + (PAR) * TILEP);                     \
     const bf16x8* Bl = reinterpret_cast<const bf16x8*>(base + (PAR) * TILEP + NPLANE * PEP);      \
     bf16x8 fa[2][2], fb[2][4];                                                                    \
-    fa[0][0] = Ah[0]; fa[0][1] = Al[0];                                                           \
-    fb[0][0] = Bh[pbase[0]]; fb[0][1] = Bl[pbase[0]];                                             \
+    fa[0][0] = Ah[0]; if (!P16) fa[0][1] = Al[0];                                                 \
+    fb[0][0] = Bh[pbase[0]]; if (!P16) fb[0][1] = Bl[pbase[0]];                                   \
     sx_static_for<4>(SX_LAMBDA(s_) { SWP_LOAD_D1(s_, n1_, oy1_) });                               \
     sx_static_for<20>(SX_LAMBDA(u_) {                                                             \
       constexpr int u = u_;                                                                       \
@@ -663,16 +692,18 @@ k_stem_wgrad_x3_pipe(const StemWgX3Args a) {
         SWP_PASS_XS(u / 4)                                                                        \
       }                                                                                           \
       bf16x8 bh, bl;                                                                              \
-      if constexpr (t == 4) { bh = shift7(fb[F][0], fb[F][2]); bl = shift7(fb[F][1], fb[F][3]); } \
-      else { bh = fb[F][0]; bl = fb[F][1]; }                                                      \
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[FA][0], bl, acc[t], 0, 0, 0);           \
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[FA][1], bh, acc[t], 0, 0, 0);           \
+      if constexpr (t == 4) { bh = shift7(fb[F][0], fb[F][2]); if (!P16) bl = shift7(fb[F][1], fb[F][3]); } \
+      else { bh = fb[F][0]; if (!P16) bl = fb[F][1]; }                                            \
+      if (!P16) {                                                                                 \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[FA][0], bl, acc[t], 0, 0, 0);         \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[FA][1], bh, acc[t], 0, 0, 0);         \
+      }                                                                                           \
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[FA][0], bh, acc[t], 0, 0, 0);           \
       if constexpr (u + 1 < 20) {                                                                 \
         constexpr int ks1 = (u + 1) / 5, t1 = (u + 1) % 5;                                        \
-        if constexpr (t1 == 0) { fa[ks1 & 1][0] = Ah[2 * ks1]; fa[ks1 & 1][1] = Al[2 * ks1]; }    \
-        fb[F ^ 1][0] = Bh[pbase[t1] + 2 * ks1]; fb[F ^ 1][1] = Bl[pbase[t1] + 2 * ks1];           \
-        if constexpr (t1 == 4) { fb[F ^ 1][2] = Bh[pbase[t1] + 2 * ks1 + 1]; fb[F ^ 1][3] = Bl[pbase[t1] + 2 * ks1 + 1]; } \
+        if constexpr (t1 == 0) { fa[ks1 & 1][0] = Ah[2 * ks1]; if (!P16) fa[ks1 & 1][1] = Al[2 * ks1]; } \
+        fb[F ^ 1][0] = Bh[pbase[t1] + 2 * ks1]; if (!P16) fb[F ^ 1][1] = Bl[pbase[t1] + 2 * ks1]; \
+        if constexpr (t1 == 4) { fb[F ^ 1][2] = Bh[pbase[t1] + 2 * ks1 + 1]; if (!P16) fb[F ^ 1][3] = Bl[pbase[t1] + 2 * ks1 + 1]; } \
       }                                                                                           \
       if constexpr (u < 16) { SWP_JOB(0, u / 4, (u % 4) * 2, (PAR) ^ 1) SWP_JOB(0, u / 4, (u % 4) * 2 + 1, (PAR) ^ 1) } \
       if constexpr (u >= 4) SWP_LOAD_X1(0, (u - 4) / 4, (u - 4) % 4, n2_, oy2_)                   \
@@ -787,7 +818,7 @@ int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int
 }
 
 // the same forward with a pre-split (PS) output: y_ps = image-0 pointer of a PS tensor (N, 64, Ho, Wo)
-int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st) {
+int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16) {
   StemX3Args a{};
   a.x = x; a.w = w; a.bias = bias; a.y = reinterpret_cast<float*>(y_ps); a.N = N; a.F = F; a.H = H; a.W = W;
   a.Ho = (H + 4 - 10) / 8 + 1; a.Wo = (W + 4 - 10) / 8 + 1; a.nrows = N * a.Ho;
@@ -797,16 +828,18 @@ int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps
   a.ps_hp = g.HP; a.ps_wp = g.WP; a.ps_plane = g.plane; a.ps_img = g.img;
   const int nblk = a.nrows < 256 ? a.nrows : 256;
   const size_t lds = (size_t)NROW * RL * 2 * 2;
-  if (hipFuncSetAttribute((const void*)k_stem_fwd_x3_pipe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds + 256)) != hipSuccess) {
+  const void* kern = p16 ? (const void*)k_stem_fwd_x3_pipe<true, true> : (const void*)k_stem_fwd_x3_pipe<true, false>;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds + 256)) != hipSuccess) {
     (void)hipGetLastError();
     return fail(FDET_ELAUNCH, "stem_fwd_ps: cannot reserve %zu bytes of LDS", 2 * lds + 256);
   }
-  hipLaunchKernelGGL(k_stem_fwd_x3_pipe<true>, dim3(nblk, 1), dim3(256), 2 * lds + 256, st, a);
+  if (p16) hipLaunchKernelGGL((k_stem_fwd_x3_pipe<true, true>), dim3(nblk, 1), dim3(256), 2 * lds + 256, st, a);
+  else hipLaunchKernelGGL((k_stem_fwd_x3_pipe<true, false>), dim3(nblk, 1), dim3(256), 2 * lds + 256, st, a);
   return check_launch("fdet_stem_fwd_ps");
 }
 
 int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W,
-                  hipStream_t st) {
+                  hipStream_t st, bool p16) {
   StemWgX3Args a{};
   a.x = x; a.dy = dy; a.N = N; a.F = F; a.H = H; a.W = W;
   a.Ho = (H + 4 - 10) / 8 + 1; a.Wo = (W + 4 - 10) / 8 + 1; a.nrows = N * a.Ho;
@@ -819,9 +852,15 @@ int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* 
                     (size_t)N * F * a.Ho * a.Wo < ((size_t)1 << 29);
   if (pipe) {     // pipelined: two plane tiles of 9-chunk planes, exactly four 16-column k-steps (48 < Wo <= 60), 32-bit byte offsets
     const size_t lds2 = ((size_t)2 * TILEP + 2 * 64 * DL + 8 * PEP) * 2;
-    { if (int rc_ = set_lds_attr((const void*)k_stem_wgrad_x3_pipe, (size_t)(lds2), __func__)) return rc_; }
-    hipLaunchKernelGGL(k_stem_wgrad_x3_pipe, dim3(nblk, FP / 64), dim3(256), lds2, st, a);
+    if (p16) {
+      { if (int rc_ = set_lds_attr((const void*)k_stem_wgrad_x3_pipe<true>, (size_t)(lds2), __func__)) return rc_; }
+      hipLaunchKernelGGL(k_stem_wgrad_x3_pipe<true>, dim3(nblk, FP / 64), dim3(256), lds2, st, a);
+    } else {
+      { if (int rc_ = set_lds_attr((const void*)k_stem_wgrad_x3_pipe<false>, (size_t)(lds2), __func__)) return rc_; }
+      hipLaunchKernelGGL(k_stem_wgrad_x3_pipe<false>, dim3(nblk, FP / 64), dim3(256), lds2, st, a);
+    }
   } else {
+    if (p16) return fail(FDET_EINVAL, "stem_wgrad (precision16): only the pipelined kernel's shapes (48 < Wo <= 60) are built");
     { if (int rc_ = set_lds_attr((const void*)k_stem_wgrad_x3, (size_t)(lds), __func__)) return rc_; }
     hipLaunchKernelGGL(k_stem_wgrad_x3, dim3(nblk, FP / 64), dim3(256), lds, st, a);
   }

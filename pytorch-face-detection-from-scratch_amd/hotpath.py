@@ -642,13 +642,13 @@ def stem_fwd(x, w, bias, y, ws, k, stride, pad, x3: bool = False):
              Nn, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_fwd")
 
 
-def stem_wgrad(x, dy, dW, db, ws, k, stride, pad, x3: bool = False):
+def stem_wgrad(x, dy, dW, db, ws, k, stride, pad, x3: bool = False, p16: bool = False):
     Nn, cin, H, W = x.shape
     F_ = dW.shape[0]
     _chk4(dW, (F_, cin, k, k), "dW")
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     _chk4(dy, (Nn, F_, Ho, Wo), "dy")
-    fn = lib().fdet_stem_wgrad_bf16x3 if x3 else lib().fdet_stem_wgrad
+    fn = lib().fdet_stem_wgrad_bf16 if (x3 and p16) else (lib().fdet_stem_wgrad_bf16x3 if x3 else lib().fdet_stem_wgrad)
     check(fn(ptr(x), ptr(dy), ptr(dW), ptr(db), ptr(ws, ws.dtype), ws.numel() * ws.element_size(),
              Nn, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_wgrad")
 

@@ -136,13 +136,14 @@ def conv3x3_ps_fwd_pool(x: PsTensor, wpk, bias, skip: PsTensor, drop_scale, pool
           "fdet_conv3x3_ps_fwd_pool")
 
 
-def pool_route_bwd_ps(dout_pooled: torch.Tensor, route8: torch.Tensor, drop_scale, dz2: PsTensor, slope: float = 0.2) -> None:
+def pool_route_bwd_ps(dout_pooled: torch.Tensor, route8: torch.Tensor, drop_scale, dz2: PsTensor, slope: float = 0.2,
+                      p16: bool = False) -> None:
     """dz2 (PS) = unpool(dout_pooled) * drop_scale * lrelu'(c) from the routing bytes."""
     N, C, H, W = dz2.shape
     if tuple(dout_pooled.shape) != (N, C, H // 2, W // 2) or tuple(route8.shape) != (N, C // 8, H // 2, W // 2, 8):
         raise ValueError("pool_route_bwd_ps: shapes")
-    check(lib().fdet_pool_route_bwd_ps(ptr(dout_pooled), ptr(route8, torch.uint8), ptr(drop_scale), dz2.data, N, C, H, W,
-                                       float(slope), stream()), "fdet_pool_route_bwd_ps")
+    check(_fn("fdet_pool_route_bwd_ps", p16)(ptr(dout_pooled), ptr(route8, torch.uint8), ptr(drop_scale), dz2.data, N, C, H, W,
+                                             float(slope), stream()), "fdet_pool_route_bwd_ps")
 
 
 def conv3x3_ps_dgrad_unpool(dz: PsTensor, wpk_bwd, dout_pooled: torch.Tensor, route8: torch.Tensor, dx: torch.Tensor,
@@ -159,13 +160,14 @@ def conv3x3_ps_dgrad_unpool(dz: PsTensor, wpk_bwd, dout_pooled: torch.Tensor, ro
                                                    N, cin, cout, H, W, float(slope), stream()), "fdet_conv3x3_ps_dgrad_unpool")
 
 
-def stem_fwd_ps(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, y: PsTensor, k: int, stride: int, pad: int) -> None:
+def stem_fwd_ps(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, y: PsTensor, k: int, stride: int, pad: int,
+                p16: bool = False) -> None:
     """PoolResnet stem (3 -> 64 channels, k10 s8 p2) with a PS output."""
     N, cin, H, W = x.shape
     F_ = int(w.shape[0])
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     _same(y, (N, F_, Ho, Wo), "stem_fwd_ps: y")
-    check(lib().fdet_stem_fwd_ps(ptr(x), ptr(w), ptr(bias), y.data, N, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_fwd_ps")
+    check(_fn("fdet_stem_fwd_ps", p16)(ptr(x), ptr(w), ptr(bias), y.data, N, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_fwd_ps")
 
 
 def _ps_ptr_array(ts):

@@ -23,8 +23,9 @@ KERNELS = {
     # one-float form is no longer a pipeline (plan_x3 routes those tiny maps to the staged kernel)
     "fdet_wgrad3x3_x3.hip": ["_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi16ELi0E", "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi16ELi1E",
                              "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi32ELi1E", "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi1ELi0ELi32ELi0E"],
-    "fdet_stem_x3.hip": ["_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb0E", "_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb1E",
-                         "_ZN12_GLOBAL__N_120k_stem_wgrad_x3_pipe"],
+    "fdet_stem_x3.hip": ["_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb0ELb0E", "_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb1ELb0E",
+                         "_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb1ELb1E", "_ZN12_GLOBAL__N_120k_stem_wgrad_x3_pipeILb0E",
+                         "_ZN12_GLOBAL__N_120k_stem_wgrad_x3_pipeILb1E"],
 }
 # The PS kernels issue LDS-DMA from asm (no register destination); their hand-counted waits are audited further down.
 

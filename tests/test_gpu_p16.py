@@ -184,6 +184,29 @@ def test_p16_block_chain_forward(env, cfg):
         assert torch.equal(v, bf(v))                         # hi planes only
 
 
+@pytest.mark.parametrize("N", [1, 3])
+def test_p16_stem(env, N):
+    """PoolResnet stem in precision16: forward = conv(bf16(x), bf16(w)) + bias stored as bf16 (PS hi plane); weight
+    gradient = fp32 sums of bf16(dy) x bf16(x) products."""
+    hp, ps = env
+    g = torch.Generator().manual_seed(N)
+    x = torch.rand(N, 3, 480, 480, generator=g)
+    w = torch.randn(64, 3, 10, 10, generator=g) * 0.05
+    b = torch.randn(64, generator=g)
+    y = ps.PsTensor(N, 64, 60, 60, "cuda")
+    ps.stem_fwd_ps(x.cuda(), w.cuda(), b.cuda(), y, 10, 8, 2, p16=True)
+    ref = F.conv2d(bf(x).double(), bf(w).double(), b.double(), stride=8, padding=2)
+    got = y.to_f32()
+    close_bf16(got, ref, "stem forward")
+    assert torch.equal(got.cpu(), bf(got.cpu()))
+    dy = torch.randn(N, 64, 60, 60, generator=g)
+    dW = torch.full((64, 3, 10, 10), float("nan"), device="cuda"); db = torch.full((64,), float("nan"), device="cuda")
+    ws = torch.empty(hp.stem_ws_bytes(N, 3, 64, 480, 480, 10, 8, 2) // 4, device="cuda")
+    hp.stem_wgrad(x.cuda(), dy.cuda(), dW, db, ws, 10, 8, 2, x3=True, p16=True)
+    close(dW, torch.nn.grad.conv2d_weight(bf(x).double(), (64, 3, 10, 10), bf(dy).double(), stride=8, padding=2))
+    close(db, dy.double().sum(dim=(0, 2, 3)))               # the bias gradient is summed from the fp32 dy
+
+
 def _redraw_u8(B, size, seed, checksum):
     x_u8 = torch.randint(0, 256, (B, 3, size, size), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
     assert int(x_u8.long().sum()) == int(checksum)
