@@ -477,6 +477,34 @@ int fdet_block_chain_bwd_ps_p16(const float* dout, const void* const* h_wpk1b, c
                                 void* const* h_dz1_ps, void* const* h_dz2_ps, float* dx, int nblocks, int N, int F,
                                 int H, int W, float slope, void* stream);
 
+/* MobileNetV3-small backbone, training pieces (round 4; models/MobilenetV3Backbone.py:49-60 trained through
+ * models/ModelMeta.py:115-227): fp32 NCHW tensors [N][C][P = H*W].  The 1x1 convs use fdet_pointwise_*_bf16x3, the head
+ * fdet_head_fwd / fdet_head_bwd.  PARITY UNPINNED (timm absent): checked against torch autograd on the CPU oracle.
+ *   stem     : timm Conv2dSame(3,16,3,stride 2) without bias (TF "SAME" padding), output ceil(H/2) x ceil(W/2); weight gradient
+ *   dw       : depthwise conv k = 3 | 5, stride 1 (pad k/2) or 2 (TF "SAME"), no bias; bwd = data + weight gradient
+ *   bn       : nn.BatchNorm2d in TRAINING mode (batch statistics over N,H,W; running = (1-momentum)*running + momentum*batch
+ *              with the unbiased variance) fused with the activation (0 none, 1 ReLU, 2 Hardswish) and an optional residual
+ *              add; bwd takes dy = d/dy and returns dz, dgamma, dbeta.  ws: fdet_mbt_bn_ws_bytes(C)
+ *   se       : timm SqueezeExcite y = x * hardsigmoid(W2 relu(W1 mean_hw(x) + b1) + b2); w1 [R,C], w2 [C,R];
+ *              pooled [N,C], hidden [N,R], pre [N,C] are kept by the forward for the backward; bwd ws: (N*C + N*R) floats */
+int fdet_mbt_stem_fwd(const float* x, const float* w, float* z, int N, int H, int W, void* stream);
+int fdet_mbt_stem_wgrad(const float* x, const float* dz, float* dW, int N, int H, int W, void* stream);
+int fdet_mbt_dw_fwd(const float* x, const float* w, float* z, int N, int C, int H, int W, int k, int s, void* stream);
+int fdet_mbt_dw_bwd(const float* x, const float* dz, const float* w, float* dx, float* dW, int N, int C, int H, int W,
+                    int k, int s, void* stream);
+size_t fdet_mbt_bn_ws_bytes(int C);
+int fdet_mbt_bn_fwd(const float* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, float* save_mean, float* save_invstd, const float* residual, float* y,
+                    void* ws, size_t ws_bytes, int N, int C, int P, int act, void* stream);
+int fdet_mbt_bn_bwd(const float* z, const float* dy, const float* gamma, const float* beta, const float* save_mean,
+                    const float* save_invstd, float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int N,
+                    int C, int P, int act, void* stream);
+int fdet_mbt_se_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* pooled,
+                    float* hidden, float* pre, float* y, int N, int C, int R, int P, void* stream);
+int fdet_mbt_se_bwd(const float* x, const float* dy, const float* pooled, const float* hidden, const float* pre,
+                    const float* w1, const float* w2, float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws,
+                    size_t ws_bytes, int N, int C, int R, int P, void* stream);
+
 /* Training head fused with the loss (round 4): ONE launch sequence for what models/PoolResnet.py:100-102 +
  * losses/YoloLoss.py:4-44 (called per image and summed, models/ModelMeta.py:173-176) + their autograd compute:
  *   y = sigmoid(conv(x * drop_scale, w) + bias);  loss_per_image[n] = yolo_loss(y[n], gt[n]);  loss_sum = sum_n;

@@ -185,3 +185,36 @@ def features(P: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
 def model_forward(P: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
     """MobilenetV3Backbone.forward(x, predict=0): (N,3,H,W) -> (N,5,H/32,W/32) (models/MobilenetV3Backbone.py:49-60)."""
     return torch.sigmoid(F.conv2d(features(P, x), P["out.weight"], P["out.bias"], padding=1))
+
+
+# ---- training mode (round 4): the same graph with BatchNorm on BATCH statistics (F.batch_norm(training=True) also updates the
+# running statistics in place, momentum 0.01 = timm's tf_ default), differentiable by torch autograd
+BN_MOMENTUM = 0.01
+
+
+def _bn_t(x, P, p):
+    return F.batch_norm(x, P[p + ".running_mean"], P[p + ".running_var"], P[p + ".weight"], P[p + ".bias"], True, BN_MOMENTUM, BN_EPS)
+
+
+def model_forward_train(P: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """MobilenetV3Backbone.forward in train() mode: (N,3,H,W) -> (N,5,H/32,W/32); P's running statistics are updated."""
+    h = F.conv2d(_same_pad(x, 3, 2), P["feature_extractor.0.weight"], None, 2)
+    h = F.hardswish(_bn_t(h, P, "feature_extractor.1"))
+    for b, (kind, ci, ce, co, k, s, act, se) in enumerate(BLOCKS):
+        p = f"feature_extractor.3.{STAGE_OF_BLOCK[b]}.{INDEX_IN_STAGE[b]}"
+        skip = h
+        if kind == "ds":
+            h = _act(_bn_t(_dw(h, P[p + ".conv_dw.weight"], k, s), P, p + ".bn1"), act)
+            if se:
+                h = _se(h, P, p + ".se")
+            h = _bn_t(F.conv2d(h, P[p + ".conv_pw.weight"]), P, p + ".bn2")
+        else:
+            h = _act(_bn_t(F.conv2d(h, P[p + ".conv_pw.weight"]), P, p + ".bn1"), act)
+            h = _act(_bn_t(_dw(h, P[p + ".conv_dw.weight"], k, s), P, p + ".bn2"), act)
+            if se:
+                h = _se(h, P, p + ".se")
+            h = _bn_t(F.conv2d(h, P[p + ".conv_pwl.weight"]), P, p + ".bn3")
+        if s == 1 and ci == co:
+            h = h + skip
+    h = F.hardswish(_bn_t(F.conv2d(h, P["feature_extractor.3.5.0.conv.weight"]), P, "feature_extractor.3.5.0.bn1"))
+    return torch.sigmoid(F.conv2d(h, P["out.weight"], P["out.bias"], padding=1))

@@ -3,9 +3,11 @@
 `timm.create_model("tf_mobilenetv3_small_100", pretrained=...)`; here the same module tree (conv_stem, bn1, act1, blocks:
 `feature_extractor.{0,1,3.<stage>.<block>...}`) is declared directly, so a state dict of the reference loads by name.
 
-The modules only hold parameters; the arithmetic runs in the HIP engine (mobilenetstack.MobileNetStack), inference
-only, bf16 with fp32 accumulation.  Training this backbone (BatchNorm batch statistics, backward) is not built:
-`forward` in training mode raises.
+The modules only hold parameters.  Inference (eval mode) runs in the bf16 NHWC engine (mobilenetstack.MobileNetStack,
+BatchNorm folded).  Training mode (round 4) runs mobilenet_train.MobileNetTrainEngine: fp32 NCHW, BatchNorm with batch
+statistics (running statistics updated in place), hand-written backward behind an autograd bridge, so that
+`ModelMeta(model=MobilenetV3Backbone(...)).training_step(batch, i)["loss"].backward(); optimizer.step()` works as it does in
+the reference (models/ModelMeta.py:115-227).
 """
 import warnings
 
@@ -14,7 +16,19 @@ import torch.nn as nn
 
 from .. import hotpath as hp
 from ..mobilenetstack import BLOCKS, BN_EPS, FEATURES, STAGES, MobileNetStack
+from ..mobilenet_train import MobileNetTrainEngine, MobileNetTrainFn
 from .BaseModel import BaseModel
+
+
+class _EngineShim:
+    """What ModelMeta / SAMSGD expect of `model.engine` (convstack.ConvStack): a hook that is called after the parameters
+    were updated behind torch's back."""
+
+    def __init__(self, model):
+        self._model = model
+
+    def mark_params_dirty(self):
+        self._model._mb_key = None
 
 
 def _bn(c):
@@ -90,6 +104,15 @@ class MobilenetV3Backbone(BaseModel):
         self.out = nn.Conv2d(FEATURES, 5, stride=(1, 1), kernel_size=(3, 3), padding=1)
         self._mb = MobileNetStack()
         self._mb_key = None
+        self._train_engine = MobileNetTrainEngine()
+        self._shim = _EngineShim(self)
+
+    @property
+    def engine(self):
+        return self._shim
+
+    def head_loss_fusable(self) -> bool:
+        return False
 
     def _packed_engine(self) -> MobileNetStack:
         sd = self.state_dict(keep_vars=True)
@@ -99,18 +122,26 @@ class MobilenetV3Backbone(BaseModel):
             self._mb_key = key
         return self._mb
 
+    def _train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Training-mode forward (batch statistics) with the autograd bridge to the hand-written backward."""
+        if not x.is_cuda:
+            raise hp.N.FdetError("the MobileNet training path runs on the GPU only (no CPU fallback): move model and input to cuda")
+        params = dict(self.named_parameters())
+        names = list(params.keys())
+        for n, p_ in params.items():
+            if p_.dtype != torch.float32 or not p_.is_contiguous():
+                raise TypeError(f"MobilenetV3Backbone: parameter {n} must be contiguous float32")
+        buffers = {n: b for n, b in self.named_buffers()}
+        return MobileNetTrainFn.apply(self._train_engine, names, buffers, x, *[params[n] for n in names])
+
     def _stack_forward(self, x: torch.Tensor) -> torch.Tensor:
         """(N,3,H,W) f32 in [0,1] or uint8 -> (N,5,S,S) sigmoid maps (what BaseModel.graphed_predict captures)."""
         if self.training:
-            raise NotImplementedError("MobilenetV3Backbone: inference only (call .eval()); BatchNorm batch statistics and the "
-                                      "backward pass of this backbone are not built")
+            return self._train_forward(x.float() / 255.0 if x.dtype == torch.uint8 else x)
         with torch.no_grad():
             return self._packed_engine().forward(x)
 
     def forward(self, x: torch.Tensor, predict: torch.Tensor = torch.tensor(0)):
-        if self.training:
-            raise NotImplementedError("MobilenetV3Backbone: inference only (call .eval()); BatchNorm batch statistics and the "
-                                      "backward pass of this backbone are not built")
         if predict == 1:
             if x.dim() == 3:
                 x = x.unsqueeze(0)

@@ -49,7 +49,7 @@ class ModelMeta(_Base):
 
     def configure_optimizers(self):
         optimizer = SAMSGD(self.parameters(), lr=self.lr)
-        optimizer.on_params_updated = self.model.engine.mark_params_dirty
+        optimizer.on_params_updated = self.model.engine.mark_params_dirty      # (MobilenetV3Backbone: its inference pack)
         self.opt = optimizer
         scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[40], gamma=0.1)
         return [optimizer], [scheduler]

@@ -321,11 +321,11 @@ def test_torchscript_export_matches_eager(golden, tmp_path):
             assert det_t.shape == det_o.shape and torch.equal(det_t.cpu(), det_o.cpu())
 
 
-def test_training_mode_and_cpu_inputs_fail_loudly(golden):
+def test_cpu_inputs_fail_loudly(golden):
     from fdet_amd import _native as N
     net = _model(golden("g13_mobilenet_weights"))
     with pytest.raises(N.FdetError):
         net(torch.rand(1, 3, 480, 480))
     net.train()
-    with pytest.raises(NotImplementedError):
-        net(torch.rand(1, 3, 480, 480).cuda())
+    with pytest.raises(N.FdetError):                       # training mode too: no CPU fallback
+        net(torch.rand(1, 3, 480, 480))
