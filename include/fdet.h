@@ -150,6 +150,11 @@ int fdet_ssd_loss_finish(const double* sums, float* loss, float* grad, size_t n_
 int fdet_ssd_reduce_bounding_boxes(const float* x, int B, const int* h_patch_sizes, int nscales, int with_priors,
                                    float prob_threshold, double iou_threshold, float img_w, float img_h,
                                    float* out, int32_t* out_counts, void* stream);
+/* the same with a caller-supplied prior table: priors [P,4] on the device (ReduceSSDBoundingBoxes(priors=...),
+ * datasets/utils.py:31-32: added to x, y, w, h after the 1/ps scaling of x, y), NULL = calculate_priors() */
+int fdet_ssd_reduce_bounding_boxes_priors(const float* x, int B, const int* h_patch_sizes, int nscales, int with_priors,
+                                          const float* priors, float prob_threshold, double iou_threshold, float img_w,
+                                          float img_h, float* out, int32_t* out_counts, void* stream);
 
 /* SSD heads (models/SSD.py:233-245,206-218): z [N,CP,ps,ps] holds Linear(C,5) of one scale in channels 0..4
  * (CP >= 5, extra channels ignored / zeroed); rows prior_start + i*ps + j of y [N,P,5] get

@@ -56,6 +56,7 @@ SIGNATURES = {
     "fdet_ssd_loss_parts": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "fdet_ssd_loss_finish": (_I, [_P, _P, _P, _SZ, _P, _SZ, _P]),
     "fdet_ssd_reduce_bounding_boxes": (_I, [_P, _I, _P, _I, _I, _F, _D, _F, _F, _P, _P, _P]),
+    "fdet_ssd_reduce_bounding_boxes_priors": (_I, [_P, _I, _P, _I, _I, _P, _F, _D, _F, _F, _P, _P, _P]),
     "fdet_ssd_head_pack_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "fdet_ssd_head_pack_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "fdet_u8_to_f32_norm": (_I, [_P, _P, _SZ, _P]),

@@ -625,8 +625,8 @@ k_ssd_scale_grad(float* __restrict__ grad, size_t n, const float* __restrict__ i
 
 // one workgroup per image: decode with priors -> threshold -> round -> greedy NMS -> xywh
 __global__ void __launch_bounds__(256)
-k_ssd_reduce(const float* __restrict__ x, const SsdScales sc, int with_priors, float pt, double thr, float fw, float fh,
-             float* __restrict__ out, int32_t* __restrict__ out_counts) {
+k_ssd_reduce(const float* __restrict__ x, const SsdScales sc, int with_priors, const float* __restrict__ priors, float pt,
+             double thr, float fw, float fh, float* __restrict__ out, int32_t* __restrict__ out_counts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = blockIdx.x, P = sc.start[sc.n];
   NmsLds L = carve(smem, P);
@@ -652,13 +652,18 @@ k_ssd_reduce(const float* __restrict__ x, const SsdScales sc, int with_priors, f
       const int ps = sc.ps[s_], loc = c - sc.start[s_];
       const int i = loc / ps, j = loc - i * ps;
       const float* r = m + (size_t)c * 5;
-      float v1 = r[1], v2 = r[2];
+      float v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
       if (with_priors) {                                             // :63-68
         const float mult = (float)(1.0 / ps);
         v1 = v1 * mult; v2 = v2 * mult;
-        v1 = v1 + (float)i * mult; v2 = v2 + (float)j * mult;
+        if (priors) {                                                // a caller-supplied (P,4) prior table (:31-32): added to all of x, y, w, h
+          const float* pr = priors + (size_t)c * 4;
+          v1 = v1 + pr[0]; v2 = v2 + pr[1]; v3 = v3 + pr[2]; v4 = v4 + pr[3];
+        } else {                                                     // calculate_priors (:36-48): (i / ps, j / ps, 0, 0)
+          v1 = v1 + (float)i * mult; v2 = v2 + (float)j * mult;
+        }
       }
-      const float X = v1 * fw, Y = v2 * fh, Wd = r[3] * fw, Hd = r[4] * fh;       // :69-70 (width, height as named there)
+      const float X = v1 * fw, Y = v2 * fh, Wd = v3 * fw, Hd = v4 * fh;           // :69-70 (width, height as named there)
       const float X2 = Wd + X, Y2 = Hd + Y;                          // :79-80
       L.score[k] = r[0];
       L.x1[k] = rintf(X); L.y1[k] = rintf(Y); L.x2[k] = rintf(X2); L.y2[k] = rintf(Y2);   // :84
@@ -756,9 +761,19 @@ extern "C" int fdet_ssd_loss_finish(const double* sums, float* loss, float* grad
   return check_launch("fdet_ssd_loss_finish");
 }
 
+// priors: NULL = the reference's calculate_priors(); else a device (P,4) table (ReduceSSDBoundingBoxes(priors=...), utils.py:31-32)
+extern "C" int fdet_ssd_reduce_bounding_boxes_priors(const float* x, int B, const int* h_patch_sizes, int nscales, int with_priors,
+                                                     const float* priors, float prob_threshold, double iou_threshold, float img_w,
+                                                     float img_h, float* out, int32_t* out_counts, void* stream);
 extern "C" int fdet_ssd_reduce_bounding_boxes(const float* x, int B, const int* h_patch_sizes, int nscales, int with_priors,
                                               float prob_threshold, double iou_threshold, float img_w, float img_h,
                                               float* out, int32_t* out_counts, void* stream) {
+  return fdet_ssd_reduce_bounding_boxes_priors(x, B, h_patch_sizes, nscales, with_priors, nullptr, prob_threshold, iou_threshold, img_w,
+                                               img_h, out, out_counts, stream);
+}
+extern "C" int fdet_ssd_reduce_bounding_boxes_priors(const float* x, int B, const int* h_patch_sizes, int nscales, int with_priors,
+                                                     const float* priors, float prob_threshold, double iou_threshold, float img_w,
+                                                     float img_h, float* out, int32_t* out_counts, void* stream) {
   FDET_REQUIRE(x && out && out_counts && B > 0, "ssd_reduce_bounding_boxes: bad arguments");
   SsdScales sc{};
   if (int rc = ssd_scales(h_patch_sizes, nscales, sc)) return rc;
@@ -766,7 +781,7 @@ extern "C" int fdet_ssd_reduce_bounding_boxes(const float* x, int B, const int* 
   const size_t lds = nms_lds_bytes(P) + (size_t)P * 4;
   FDET_REQUIRE(lds <= 160 * 1024, "ssd_reduce_bounding_boxes: %d priors need %zu bytes of LDS (> 160 KB)", P, lds);
   if (int rc = set_lds(k_ssd_reduce, lds)) return rc;
-  hipLaunchKernelGGL(k_ssd_reduce, dim3(B), dim3(256), lds, (hipStream_t)stream, x, sc, with_priors, prob_threshold,
+  hipLaunchKernelGGL(k_ssd_reduce, dim3(B), dim3(256), lds, (hipStream_t)stream, x, sc, with_priors, priors, prob_threshold,
                      iou_threshold, img_w, img_h, out, out_counts);
   return check_launch("fdet_ssd_reduce_bounding_boxes");
 }

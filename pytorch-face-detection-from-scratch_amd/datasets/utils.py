@@ -14,8 +14,7 @@ class ReduceSSDBoundingBoxes(nn.Module):
     def __init__(self, probability_threshold: float = 0.9, iou_threshold: float = 0.5, input_shape=(3, 320, 240),
                  patch_sizes=(60, 30, 15, 7), priors=None, with_priors=False):
         super().__init__()
-        if priors is not None:
-            raise NotImplementedError("custom priors are not supported: the kernel derives them from patch_sizes")
+        self.priors = priors                                 # (P,4) table or None = calculate_priors() inside the kernel (:31-34)
         self.probability_threshold = probability_threshold
         self.iou_threshold = iou_threshold
         self.input_shape = input_shape
@@ -26,7 +25,7 @@ class ReduceSSDBoundingBoxes(nn.Module):
     def forward_batch(self, x: torch.Tensor):
         """(B,P,5) -> (rows (B,P,5) [score,x,y,w,h], counts (B,)), on the GPU, no host sync."""
         return hp.ssd_reduce_bounding_boxes(x, self.probability_threshold, self.iou_threshold, self.width, self.height,
-                                            self.patch_sizes, self.with_priors)
+                                            self.patch_sizes, self.with_priors, self.priors)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rows, counts = self.forward_batch(x.unsqueeze(0))

@@ -206,8 +206,9 @@ def ssd_loss_finish(sums: torch.Tensor, grad: Optional[torch.Tensor]) -> torch.T
 
 
 def ssd_reduce_bounding_boxes(x: torch.Tensor, prob_threshold: float, iou_threshold: float, img_w: float, img_h: float,
-                              patch_sizes=SSD_PATCH_SIZES, with_priors: bool = True):
-    """Batched ReduceSSDBoundingBoxes.forward: (B,P,5) -> (rows (B,P,5), counts (B,))."""
+                              patch_sizes=SSD_PATCH_SIZES, with_priors: bool = True, priors: torch.Tensor = None):
+    """Batched ReduceSSDBoundingBoxes.forward: (B,P,5) -> (rows (B,P,5), counts (B,)).  priors: optional (P,4) table
+    (datasets/utils.py:31-32), None = the reference's calculate_priors()."""
     x = _f32(x)
     B, P, five = x.shape
     if five != 5 or P != ssd_num_priors(patch_sizes):
@@ -215,9 +216,13 @@ def ssd_reduce_bounding_boxes(x: torch.Tensor, prob_threshold: float, iou_thresh
     arr, ns = _ps_array(patch_sizes)
     out = torch.zeros(B, P, 5, dtype=F32, device=x.device)
     counts = torch.zeros(B, dtype=I32, device=x.device)
-    check(lib().fdet_ssd_reduce_bounding_boxes(ptr(x), B, arr, ns, int(bool(with_priors)), float(prob_threshold),
-                                               float(iou_threshold), float(img_w), float(img_h), ptr(out),
-                                               ptr(counts, I32), stream()), "fdet_ssd_reduce_bounding_boxes")
+    if priors is not None:
+        priors = _f32(priors.to(x.device))
+        if tuple(priors.shape) != (P, 4):
+            raise ValueError(f"ssd_reduce_bounding_boxes: priors must be ({P},4), got {tuple(priors.shape)}")
+    check(lib().fdet_ssd_reduce_bounding_boxes_priors(ptr(x), B, arr, ns, int(bool(with_priors)), ptr(priors), float(prob_threshold),
+                                                      float(iou_threshold), float(img_w), float(img_h), ptr(out),
+                                                      ptr(counts, I32), stream()), "fdet_ssd_reduce_bounding_boxes")
     return out, counts
 
 

@@ -148,6 +148,10 @@ class GraphedPredict:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.rows, self.counts = self._run()
+        # the captured launches hold raw pointers into the engine's pooled PS buffers: keep those buffers alive for as long
+        # as the graph is (the engine drops its pool when the batch size changes)
+        eng = getattr(model, "_engine", None)
+        self._pool_refs = [t for lst in getattr(eng, "_ps_pool", {}).values() for t in lst] if eng is not None else []
 
     def _run(self):
         m = self.model

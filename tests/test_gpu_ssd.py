@@ -50,6 +50,27 @@ def test_ssd_reduce_matches_reference(hp, golden):
         assert torch.equal(rows[n, :k].cpu(), g["dec_out"][n, :k])
 
 
+def test_ssd_reduce_with_custom_priors(hp):
+    """ReduceSSDBoundingBoxes(priors=table) (datasets/utils.py:31-32): the caller's (P,4) table replaces calculate_priors();
+    it is added to x, y AND w, h.  Module surface and oracle, box for box."""
+    from fdet_amd.datasets.utils import ReduceSSDBoundingBoxes
+    gen = torch.Generator().manual_seed(5)
+    P = hp.ssd_num_priors()
+    _, base = S.ssd_priors()
+    table = base + torch.cat([torch.rand(P, 2, generator=gen) * 0.01, torch.rand(P, 2, generator=gen) * 0.05], 1)
+    x = torch.rand(3, P, 5, generator=gen) * torch.tensor([0.505, 1, 1, 0.3, 0.3])
+    red = ReduceSSDBoundingBoxes(0.5, 0.3, (3, SIZE, SIZE), priors=table, with_priors=True)
+    rows, counts = red.forward_batch(x.cuda())
+    for i in range(3):
+        want = S.reduce_ssd_bounding_boxes(x[i], 0.5, 0.3, (3, SIZE, SIZE), with_priors=True, priors=table)
+        assert int(counts[i]) == want.shape[0] and want.shape[0] > 0
+        assert torch.equal(rows[i, : want.shape[0]].cpu(), want)
+    # the default table is what the kernel derives by itself
+    r2, c2 = ReduceSSDBoundingBoxes(0.5, 0.3, (3, SIZE, SIZE), priors=base, with_priors=True).forward_batch(x.cuda())
+    r3, c3 = ReduceSSDBoundingBoxes(0.5, 0.3, (3, SIZE, SIZE), with_priors=True).forward_batch(x.cuda())
+    assert torch.equal(c2, c3) and torch.equal(r2, r3)
+
+
 def test_ssd_batch_vs_oracle(hp):
     """64 images: encode -> loss on random predictions -> reducer, every image against the oracle."""
     B = 64
