@@ -19,6 +19,7 @@ int stem_mfma_fwd(const float* x, const float* w, const float* bias, float* y, i
 int stem_mfma_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st);
 int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W, hipStream_t st);   // fdet_stem_x3.hip
 int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16);
+int stem_dma_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16);
 int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st, bool p16);
 }
 
@@ -369,6 +370,8 @@ extern "C" int fdet_stem_fwd_ps(const float* x, const float* w, const float* bia
   FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad),
                "stem_fwd_ps: only the PoolResnet stem (3ch k10 s8 p2, W%%4==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
                Cin, k, stride, pad, W);
+  { const char* e = FDET_ENV_ONCE("FDET_STEM_DMA");        // the LDS-DMA form (fdet_stem_dma.hip)
+    if (e && e[0] == '1') { const int rc = stem_dma_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, false); if (rc != 1) return rc; } }
   return stem_x3_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, false);
 }
 
@@ -379,6 +382,8 @@ extern "C" int fdet_stem_fwd_ps_p16(const float* x, const float* w, const float*
   FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad),
                "stem_fwd_ps_p16: only the PoolResnet stem (3ch k10 s8 p2, W%%4==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
                Cin, k, stride, pad, W);
+  { const char* e = FDET_ENV_ONCE("FDET_STEM_DMA");
+    if (e && e[0] == '1') { const int rc = stem_dma_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, true); if (rc != 1) return rc; } }
   return stem_x3_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, true);
 }
 
