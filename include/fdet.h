@@ -491,12 +491,13 @@ int fdet_block_chain_bwd_ps_p16(const float* dout, const void* const* h_wpk1b, c
  *              with the unbiased variance) fused with the activation (0 none, 1 ReLU, 2 Hardswish) and an optional residual
  *              add; bwd takes dy = d/dy and returns dz, dgamma, dbeta.  ws: fdet_mbt_bn_ws_bytes(C)
  *   se       : timm SqueezeExcite y = x * hardsigmoid(W2 relu(W1 mean_hw(x) + b1) + b2); w1 [R,C], w2 [C,R];
- *              pooled [N,C], hidden [N,R], pre [N,C] are kept by the forward for the backward; bwd ws: (N*C + N*R) floats */
+ *              pooled [N,C], hidden [N,R], pre [N,C] are kept by the forward for the backward; bwd ws: (2*N*C + N*R) floats */
 int fdet_mbt_stem_fwd(const float* x, const float* w, float* z, int N, int H, int W, void* stream);
-int fdet_mbt_stem_wgrad(const float* x, const float* dz, float* dW, int N, int H, int W, void* stream);
+size_t fdet_mbt_taps_ws_bytes(int C, int k);   /* workspace of the tap-gradient kernels; k = 0: the stem (C = 16, 27 taps) */
+int fdet_mbt_stem_wgrad(const float* x, const float* dz, float* dW, void* ws, size_t ws_bytes, int N, int H, int W, void* stream);
 int fdet_mbt_dw_fwd(const float* x, const float* w, float* z, int N, int C, int H, int W, int k, int s, void* stream);
-int fdet_mbt_dw_bwd(const float* x, const float* dz, const float* w, float* dx, float* dW, int N, int C, int H, int W,
-                    int k, int s, void* stream);
+int fdet_mbt_dw_bwd(const float* x, const float* dz, const float* w, float* dx, float* dW, void* ws, size_t ws_bytes, int N,
+                    int C, int H, int W, int k, int s, void* stream);
 size_t fdet_mbt_bn_ws_bytes(int C);
 int fdet_mbt_bn_fwd(const float* z, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     float momentum, float eps, float* save_mean, float* save_invstd, const float* residual, float* y,

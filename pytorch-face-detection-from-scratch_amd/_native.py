@@ -131,9 +131,10 @@ SIGNATURES = {
     "fdet_block_chain_fwd_ps_p16": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_block_chain_bwd_ps_p16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_mbt_stem_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "fdet_mbt_stem_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "fdet_mbt_taps_ws_bytes": (_SZ, [_I, _I]),
+    "fdet_mbt_stem_wgrad": (_I, [_P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "fdet_mbt_dw_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "fdet_mbt_dw_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fdet_mbt_dw_bwd": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_mbt_bn_ws_bytes": (_SZ, [_I]),
     "fdet_mbt_bn_fwd": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
     "fdet_mbt_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),

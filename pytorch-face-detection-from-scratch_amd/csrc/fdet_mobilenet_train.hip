@@ -77,23 +77,53 @@ k_mbt_stem_fwd(const float* __restrict__ x, const float* __restrict__ w, float* 
   for (int c = 0; c < 16; ++c) z[(((size_t)n * 16 + c) * Ho + oy) * Wo + ox] = acc[c];
 }
 
-// dW[c][ci][ky][kx] = sum_{n,oy,ox} dz[n][c][oy][ox] * x[n][ci][2oy - pt + ky][2ox - pl + kx]; one block per (c, tap), fixed order
-__global__ void __launch_bounds__(1024)
-k_mbt_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dW, int N, int H, int W, int Ho,
+// dW[c][ci][ky][kx] = sum_{n,oy,ox} dz[n][c][oy][ox] * x[n][ci][2oy - pt + ky][2ox - pl + kx].  One block per (channel, slice of
+// the (n, oy, ox) space): a thread reads dz once per position and keeps all 27 taps in registers; block partials in fp64, the
+// slices are added in fixed order by k_mbt_taps_finish.
+constexpr int TAP_SPLIT = 64;
+__global__ void __launch_bounds__(256)
+k_mbt_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dz, double* __restrict__ part, int N, int H, int W, int Ho,
                  int Wo, int pt, int pl) {
   __shared__ double sh[16];
-  const int c = blockIdx.x / 27, tap = blockIdx.x % 27;
-  const int ci = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-  double s = 0.0;
+  const int c = blockIdx.x, j = blockIdx.y;
   const long long total = (long long)N * Ho * Wo;
-  for (long long t = threadIdx.x; t < total; t += 1024) {
+  const long long lo = total * j / TAP_SPLIT, hi = total * (j + 1) / TAP_SPLIT;
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  for (long long t = lo + threadIdx.x; t < hi; t += 256) {
     const int ox = (int)(t % Wo), oy = (int)((t / Wo) % Ho), n = (int)(t / ((long long)Wo * Ho));
-    const int iy = oy * 2 - pt + ky, ix = ox * 2 - pl + kx;
-    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-    s += (double)dz[(((size_t)n * 16 + c) * Ho + oy) * Wo + ox] * (double)x[(((size_t)n * 3 + ci) * H + iy) * W + ix];
+    const float g = dz[(((size_t)n * 16 + c) * Ho + oy) * Wo + ox];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - pt + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = ox * 2 - pl + kx;
+          const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+          const float v = ok ? x[(((size_t)n * 3 + ci) * H + iy) * W + ix] : 0.f;
+          acc[(ci * 3 + ky) * 3 + kx] = fmaf(g, v, acc[(ci * 3 + ky) * 3 + kx]);
+        }
+      }
   }
-  const double tot = block_sum(s, sh);
-  if (threadIdx.x == 0) dW[c * 27 + tap] = (float)tot;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    const double tot = block_sum((double)acc[t], sh);
+    if (threadIdx.x == 0) part[((size_t)c * TAP_SPLIT + j) * 27 + t] = tot;
+  }
+}
+
+// out[c * ntap + t] = sum_j part[(c * TAP_SPLIT + j) * ntap + t]   (fixed order)
+__global__ void __launch_bounds__(256)
+k_mbt_taps_finish(const double* __restrict__ part, float* __restrict__ out, int C, int ntap) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * ntap) return;
+  const int c = i / ntap, t = i % ntap;
+  double s = 0.0;
+  for (int j = 0; j < TAP_SPLIT; ++j) s += part[((size_t)c * TAP_SPLIT + j) * ntap + t];
+  out[i] = (float)s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -152,25 +182,40 @@ k_mbt_dw_bwd_data(const float* __restrict__ dz, const float* __restrict__ w, flo
   dx[t] = acc;
 }
 
-// dW[c][ky][kx] = sum_{n,oy,ox} dz * x: one block per (c, tap), fixed order
-__global__ void __launch_bounds__(1024)
-k_mbt_dw_bwd_weight(const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dW, int N, int C, int H, int W,
-                    int Ho, int Wo, int k, int s, int pt, int pl) {
+// dW[c][ky][kx] = sum_{n,oy,ox} dz * x: one block per (channel, slice); a thread keeps the k*k taps of its positions
+template <int K>
+__global__ void __launch_bounds__(256)
+k_mbt_dw_bwd_weight(const float* __restrict__ x, const float* __restrict__ dz, double* __restrict__ part, int N, int C, int H, int W,
+                    int Ho, int Wo, int s, int pt, int pl) {
   __shared__ double sh[16];
-  const int kk = k * k;
-  const int c = blockIdx.x / kk, tap = blockIdx.x % kk;
-  const int ky = tap / k, kx = tap % k;
-  double acc = 0.0;
+  constexpr int kk = K * K;
+  const int c = blockIdx.x, j = blockIdx.y;
   const long long per = (long long)Ho * Wo, total = (long long)N * per;
-  for (long long t = threadIdx.x; t < total; t += 1024) {
+  const long long lo = total * j / TAP_SPLIT, hi = total * (j + 1) / TAP_SPLIT;
+  float acc[kk];
+#pragma unroll
+  for (int t = 0; t < kk; ++t) acc[t] = 0.f;
+  for (long long t = lo + threadIdx.x; t < hi; t += 256) {
     const int n = (int)(t / per);
     const int r = (int)(t % per), oy = r / Wo, ox = r % Wo;
-    const int iy = oy * s - pt + ky, ix = ox * s - pl + kx;
-    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-    acc += (double)dz[((size_t)n * C + c) * per + r] * (double)x[(((size_t)n * C + c) * H + iy) * W + ix];
+    const float g = dz[((size_t)n * C + c) * per + r];
+    const float* xp = x + ((size_t)n * C + c) * H * W;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * s - pt + ky;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int ix = ox * s - pl + kx;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        acc[ky * K + kx] = fmaf(g, ok ? xp[(size_t)iy * W + ix] : 0.f, acc[ky * K + kx]);
+      }
+    }
   }
-  const double tot = block_sum(acc, sh);
-  if (threadIdx.x == 0) dW[(size_t)c * kk + tap] = (float)tot;
+#pragma unroll
+  for (int t = 0; t < kk; ++t) {
+    const double tot = block_sum((double)acc[t], sh);
+    if (threadIdx.x == 0) part[((size_t)c * TAP_SPLIT + j) * kk + t] = tot;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -284,32 +329,38 @@ k_mbt_bn_bwd_apply(const float* __restrict__ z, const float* __restrict__ dy, co
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float hsig(float v) { return fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f; }
 
+// mean over H*W of every (n, c) plane: one wave per plane (fixed order)
 __global__ void __launch_bounds__(256)
-k_mbt_se_gate(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-              const float* __restrict__ b2, float* __restrict__ pooled, float* __restrict__ hidden, float* __restrict__ pre,
-              int C, int R, int P) {
+k_mbt_se_pool(const float* __restrict__ x, float* __restrict__ pooled, int NC, int P) {
+  const int lane = threadIdx.x & 63;
+  const int pl = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pl >= NC) return;
+  const float* xp = x + (size_t)pl * P;
+  float s = 0.f;
+  for (int p = lane; p < P; p += 64) s += xp[p];
+  s = wave_sum(s);
+  if (lane == 0) pooled[pl] = s / (float)P;
+}
+
+// the two tiny FC layers of one image: hidden = W1 pooled + b1 (kept pre-ReLU), pre = W2 relu(hidden) + b2
+__global__ void __launch_bounds__(256)
+k_mbt_se_fc(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+            const float* __restrict__ b2, float* __restrict__ hidden, float* __restrict__ pre, int C, int R) {
   extern __shared__ float smf[];                         // pooled[C] | hidden[R]
   float* sp = smf; float* shd = smf + C;
-  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int c = wv; c < C; c += 4) {                      // a wave per channel: fixed-order mean
-    const float* xp = x + ((size_t)n * C + c) * P;
-    float s = 0.f;
-    for (int p = lane; p < P; p += 64) s += xp[p];
-    s = wave_sum(s);
-    if (lane == 0) { const float m = s / (float)P; sp[c] = m; pooled[(size_t)n * C + c] = m; }
-  }
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) sp[c] = pooled[(size_t)n * C + c];
   __syncthreads();
   for (int r = threadIdx.x; r < R; r += 256) {
     float a = b1[r];
     for (int c = 0; c < C; ++c) a = fmaf(w1[(size_t)r * C + c], sp[c], a);
-    const float h = a > 0.f ? a : 0.f;
-    shd[r] = h; hidden[(size_t)n * R + r] = a;           // pre-ReLU value kept (its sign is the derivative)
+    shd[r] = a > 0.f ? a : 0.f; hidden[(size_t)n * R + r] = a;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float a = b2[c];
     for (int r = 0; r < R; ++r) a = fmaf(w2[(size_t)c * R + r], shd[r], a);
-    pre[(size_t)n * C + c] = a;                          // pre-hardsigmoid value
+    pre[(size_t)n * C + c] = a;
   }
 }
 
@@ -320,48 +371,52 @@ k_mbt_se_scale(const float* __restrict__ x, const float* __restrict__ pre, float
   y[t] = x[t] * hsig(pre[t / P]);
 }
 
-// backward: dgate[n][c] = sum_p dy * x; through hardsigmoid', W2^T, relu', W1^T -> dpool; dx = dy * gate + dpool / P;
-// per-image partials of the FC gradients (reduced in fixed order by k_mbt_se_wreduce)
+// backward 1: dpre[n][c] = hardsigmoid'(pre) * sum_p dy * x  (one wave per plane)
 __global__ void __launch_bounds__(256)
-k_mbt_se_bwd(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ pooled,
-             const float* __restrict__ hidden, const float* __restrict__ pre, const float* __restrict__ w1,
-             const float* __restrict__ w2, float* __restrict__ dx, float* __restrict__ dpre_out, float* __restrict__ dhid_out,
-             int C, int R, int P) {
-  extern __shared__ float smf[];                         // dpre[C] | dhid[R] | dpool[C]
-  float* sdpre = smf; float* sdh = smf + C; float* sdp = smf + C + R;
-  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int c = wv; c < C; c += 4) {
-    const float* xp = x + ((size_t)n * C + c) * P;
-    const float* gp = dy + ((size_t)n * C + c) * P;
-    float s = 0.f;
-    for (int p = lane; p < P; p += 64) s = fmaf(gp[p], xp[p], s);
-    s = wave_sum(s);
-    if (lane == 0) {
-      const float a = pre[(size_t)n * C + c];
-      const float d = (a > -3.f && a < 3.f) ? s * (1.f / 6.f) : 0.f;      // hardsigmoid'
-      sdpre[c] = d; dpre_out[(size_t)n * C + c] = d;
-    }
-  }
+k_mbt_se_bwd_gate(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre,
+                  int NC, int P) {
+  const int lane = threadIdx.x & 63;
+  const int pl = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pl >= NC) return;
+  const float* xp = x + (size_t)pl * P;
+  const float* gp = dy + (size_t)pl * P;
+  float s = 0.f;
+  for (int p = lane; p < P; p += 64) s = fmaf(gp[p], xp[p], s);
+  s = wave_sum(s);
+  if (lane == 0) { const float a = pre[pl]; dpre[pl] = (a > -3.f && a < 3.f) ? s * (1.f / 6.f) : 0.f; }
+}
+
+// backward 2 (per image): dhid = relu'(hidden) * W2^T dpre ; dpool = W1^T dhid / P
+__global__ void __launch_bounds__(256)
+k_mbt_se_bwd_fc(const float* __restrict__ dpre, const float* __restrict__ hidden, const float* __restrict__ w1,
+                const float* __restrict__ w2, float* __restrict__ dhid, float* __restrict__ dpool, int C, int R, int P) {
+  extern __shared__ float smf[];                         // dpre[C] | dhid[R]
+  float* sdpre = smf; float* sdh = smf + C;
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) sdpre[c] = dpre[(size_t)n * C + c];
   __syncthreads();
   for (int r = threadIdx.x; r < R; r += 256) {
     float a = 0.f;
     for (int c = 0; c < C; ++c) a = fmaf(w2[(size_t)c * R + r], sdpre[c], a);
-    const float d = hidden[(size_t)n * R + r] > 0.f ? a : 0.f;            // relu'
-    sdh[r] = d; dhid_out[(size_t)n * R + r] = d;
+    const float d = hidden[(size_t)n * R + r] > 0.f ? a : 0.f;
+    sdh[r] = d; dhid[(size_t)n * R + r] = d;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float a = 0.f;
     for (int r = 0; r < R; ++r) a = fmaf(w1[(size_t)r * C + c], sdh[r], a);
-    sdp[c] = a / (float)P;
+    dpool[(size_t)n * C + c] = a / (float)P;
   }
-  __syncthreads();
-  const long long per = (long long)C * P;
-  for (long long t = threadIdx.x; t < per; t += 256) {
-    const int c = (int)(t / P);
-    const size_t e = (size_t)n * per + t;
-    dx[e] = dy[e] * hsig(pre[(size_t)n * C + c]) + sdp[c];
-  }
+}
+
+// backward 3: dx = dy * hardsigmoid(pre) + dpool
+__global__ void __launch_bounds__(256)
+k_mbt_se_bwd_apply(const float* __restrict__ dy, const float* __restrict__ pre, const float* __restrict__ dpool, float* __restrict__ dx,
+                   int P, long long total) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const long long pl = t / P;
+  dx[t] = dy[t] * hsig(pre[pl]) + dpool[pl];
 }
 
 // dW2[c][r] = sum_n dpre[n][c] * relu(hidden[n][r]); db2[c] = sum_n dpre; dW1[r][c] = sum_n dhid[n][r] * pooled[n][c]; db1[r] = sum_n dhid
@@ -408,11 +463,19 @@ extern "C" int fdet_mbt_stem_fwd(const float* x, const float* w, float* z, int N
   return check_launch("fdet_mbt_stem_fwd");
 }
 
-extern "C" int fdet_mbt_stem_wgrad(const float* x, const float* dz, float* dW, int N, int H, int W, void* stream) {
-  FDET_REQUIRE(x && dz && dW && N > 0, "mbt_stem_wgrad: bad arguments");
+extern "C" size_t fdet_mbt_taps_ws_bytes(int C, int k) { return (size_t)C * TAP_SPLIT * (k == 0 ? 27 : k * k) * sizeof(double); }
+
+// ws: fdet_mbt_taps_ws_bytes(16, 0) bytes
+extern "C" int fdet_mbt_stem_wgrad(const float* x, const float* dz, float* dW, void* ws, size_t ws_bytes, int N, int H, int W,
+                                   void* stream) {
+  FDET_REQUIRE(x && dz && dW && ws && N > 0, "mbt_stem_wgrad: bad arguments");
+  FDET_REQUIRE(ws_bytes >= fdet_mbt_taps_ws_bytes(16, 0), "mbt_stem_wgrad: workspace too small");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  hipLaunchKernelGGL(k_mbt_stem_wgrad, dim3(16 * 27), dim3(1024), 0, (hipStream_t)stream, x, dz, dW, N, H, W, Ho, Wo,
+  hipStream_t st = (hipStream_t)stream;
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(k_mbt_stem_wgrad, dim3(16, TAP_SPLIT), dim3(256), 0, st, x, dz, part, N, H, W, Ho, Wo,
                      same_pad_front(H, 3, 2), same_pad_front(W, 3, 2));
+  hipLaunchKernelGGL(k_mbt_taps_finish, dim3((16 * 27 + 255) / 256), dim3(256), 0, st, part, dW, 16, 27);
   return check_launch("fdet_mbt_stem_wgrad");
 }
 
@@ -433,14 +496,19 @@ extern "C" int fdet_mbt_dw_fwd(const float* x, const float* w, float* z, int N, 
   return check_launch("fdet_mbt_dw_fwd");
 }
 
-extern "C" int fdet_mbt_dw_bwd(const float* x, const float* dz, const float* w, float* dx, float* dW, int N, int C, int H, int W,
-                               int k, int s, void* stream) {
+// ws: fdet_mbt_taps_ws_bytes(C, k) bytes
+extern "C" int fdet_mbt_dw_bwd(const float* x, const float* dz, const float* w, float* dx, float* dW, void* ws, size_t ws_bytes, int N,
+                               int C, int H, int W, int k, int s, void* stream) {
   int Ho, Wo, pt, pl;
-  FDET_REQUIRE(x && dz && w && dx && dW && N > 0 && C > 0 && dw_geo(H, W, k, s, Ho, Wo, pt, pl), "mbt_dw_bwd: bad arguments");
+  FDET_REQUIRE(x && dz && w && dx && dW && ws && N > 0 && C > 0 && dw_geo(H, W, k, s, Ho, Wo, pt, pl), "mbt_dw_bwd: bad arguments");
+  FDET_REQUIRE(ws_bytes >= fdet_mbt_taps_ws_bytes(C, k), "mbt_dw_bwd: workspace too small");
   const long long total = (long long)N * C * H * W;
   hipStream_t st = (hipStream_t)stream;
+  double* part = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(k_mbt_dw_bwd_data, dim3(nblk(total, 256)), dim3(256), 0, st, dz, w, dx, N, C, H, W, Ho, Wo, k, s, pt, pl);
-  hipLaunchKernelGGL(k_mbt_dw_bwd_weight, dim3(C * k * k), dim3(1024), 0, st, x, dz, dW, N, C, H, W, Ho, Wo, k, s, pt, pl);
+  if (k == 3) hipLaunchKernelGGL(k_mbt_dw_bwd_weight<3>, dim3(C, TAP_SPLIT), dim3(256), 0, st, x, dz, part, N, C, H, W, Ho, Wo, s, pt, pl);
+  else hipLaunchKernelGGL(k_mbt_dw_bwd_weight<5>, dim3(C, TAP_SPLIT), dim3(256), 0, st, x, dz, part, N, C, H, W, Ho, Wo, s, pt, pl);
+  hipLaunchKernelGGL(k_mbt_taps_finish, dim3((C * k * k + 255) / 256), dim3(256), 0, st, part, dW, C, k * k);
   return check_launch("fdet_mbt_dw_bwd");
 }
 
@@ -488,22 +556,27 @@ extern "C" int fdet_mbt_se_fwd(const float* x, const float* w1, const float* b1,
                                float* hidden, float* pre, float* y, int N, int C, int R, int P, void* stream) {
   FDET_REQUIRE(x && w1 && b1 && w2 && b2 && pooled && hidden && pre && y && N > 0 && C > 0 && R > 0 && P > 0, "mbt_se_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_mbt_se_gate, dim3(N), dim3(256), (size_t)(C + R) * 4, st, x, w1, b1, w2, b2, pooled, hidden, pre, C, R, P);
+  hipLaunchKernelGGL(k_mbt_se_pool, dim3((N * C + 3) / 4), dim3(256), 0, st, x, pooled, N * C, P);
+  hipLaunchKernelGGL(k_mbt_se_fc, dim3(N), dim3(256), (size_t)(C + R) * 4, st, pooled, w1, b1, w2, b2, hidden, pre, C, R);
   const long long total = (long long)N * C * P;
   hipLaunchKernelGGL(k_mbt_se_scale, dim3(nblk(total, 256)), dim3(256), 0, st, x, pre, y, P, total);
   return check_launch("fdet_mbt_se_fwd");
 }
 
-// ws: (N*C + N*R) floats
+// ws: (2*N*C + N*R) floats
 extern "C" int fdet_mbt_se_bwd(const float* x, const float* dy, const float* pooled, const float* hidden, const float* pre,
                                const float* w1, const float* w2, float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws,
                                size_t ws_bytes, int N, int C, int R, int P, void* stream) {
   FDET_REQUIRE(x && dy && pooled && hidden && pre && w1 && w2 && dx && dw1 && db1 && dw2 && db2 && ws && N > 0, "mbt_se_bwd: bad arguments");
-  FDET_REQUIRE(ws_bytes >= ((size_t)N * C + (size_t)N * R) * 4, "mbt_se_bwd: workspace too small");
+  FDET_REQUIRE(ws_bytes >= ((size_t)2 * N * C + (size_t)N * R) * 4, "mbt_se_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* dpre = reinterpret_cast<float*>(ws);
   float* dhid = dpre + (size_t)N * C;
-  hipLaunchKernelGGL(k_mbt_se_bwd, dim3(N), dim3(256), (size_t)(2 * C + R) * 4, st, x, dy, pooled, hidden, pre, w1, w2, dx, dpre, dhid, C, R, P);
+  float* dpool = dhid + (size_t)N * R;
+  hipLaunchKernelGGL(k_mbt_se_bwd_gate, dim3((N * C + 3) / 4), dim3(256), 0, st, x, dy, pre, dpre, N * C, P);
+  hipLaunchKernelGGL(k_mbt_se_bwd_fc, dim3(N), dim3(256), (size_t)(C + R) * 4, st, dpre, hidden, w1, w2, dhid, dpool, C, R, P);
+  { const long long total = (long long)N * C * P;
+    hipLaunchKernelGGL(k_mbt_se_bwd_apply, dim3(nblk(total, 256)), dim3(256), 0, st, dy, pre, dpool, dx, P, total); }
   const int tot = 2 * C * R + C + R;
   hipLaunchKernelGGL(k_mbt_se_wreduce, dim3((tot + 255) / 256), dim3(256), 0, st, dpre, dhid, pooled, hidden, dw1, db1, dw2, db2, N, C, R);
   return check_launch("fdet_mbt_se_bwd");

@@ -70,7 +70,9 @@ def dw_fwd(x, w, k: int, s: int):
 def dw_bwd(x, dz, w, k: int, s: int, dW):
     N, C, H, W = x.shape
     dx = torch.empty_like(x)
-    check(lib().fdet_mbt_dw_bwd(ptr(x), ptr(dz), ptr(w), ptr(dx), ptr(dW), N, C, H, W, k, s, stream()), "fdet_mbt_dw_bwd")
+    ws = torch.empty(int(lib().fdet_mbt_taps_ws_bytes(C, k)) // 4 + 4, dtype=F32, device=x.device)
+    check(lib().fdet_mbt_dw_bwd(ptr(x), ptr(dz), ptr(w), ptr(dx), ptr(dW), ptr(ws), ws.numel() * 4, N, C, H, W, k, s, stream()),
+          "fdet_mbt_dw_bwd")
     return dx
 
 
@@ -111,7 +113,7 @@ def se_bwd(x, dy, P, p, kept, G):
     N, C, H, W = x.shape
     R = P[p + ".conv_reduce.weight"].shape[0]
     dx = torch.empty_like(x)
-    ws = torch.empty(N * C + N * R + 4, dtype=F32, device=x.device)
+    ws = torch.empty(2 * N * C + N * R + 4, dtype=F32, device=x.device)
     check(lib().fdet_mbt_se_bwd(ptr(x), ptr(dy), ptr(kept[0]), ptr(kept[1]), ptr(kept[2]), ptr(P[p + ".conv_reduce.weight"]),
                                 ptr(P[p + ".conv_expand.weight"]), ptr(dx), ptr(G[p + ".conv_reduce.weight"]), ptr(G[p + ".conv_reduce.bias"]),
                                 ptr(G[p + ".conv_expand.weight"]), ptr(G[p + ".conv_expand.bias"]), ptr(ws), ws.numel() * 4, N, C, R,
@@ -203,8 +205,9 @@ class MobileNetTrainEngine:
         z, st = S["stem"]
         dzs = bn_bwd(z, dh, P, "feature_extractor.1", st, ACT["hswish"], G)
         x = S["x"]
-        check(lib().fdet_mbt_stem_wgrad(ptr(x), ptr(dzs), ptr(G["feature_extractor.0.weight"]), x.shape[0], x.shape[2], x.shape[3], stream()),
-              "fdet_mbt_stem_wgrad")
+        wst = torch.empty(int(lib().fdet_mbt_taps_ws_bytes(16, 0)) // 4 + 4, dtype=F32, device=x.device)
+        check(lib().fdet_mbt_stem_wgrad(ptr(x), ptr(dzs), ptr(G["feature_extractor.0.weight"]), ptr(wst), wst.numel() * 4, x.shape[0],
+                                        x.shape[2], x.shape[3], stream()), "fdet_mbt_stem_wgrad")
 
 
 def learnable_names(state_names: List[str]) -> List[str]:

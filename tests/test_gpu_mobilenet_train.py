@@ -47,7 +47,9 @@ def test_stem_fwd_and_wgrad(L, shape):
     ref.backward(dz)
     dW = torch.full((16, 3, 3, 3), float("nan"), device="cuda")
     dzd = dz.cuda()
-    N_.check(N_.lib().fdet_mbt_stem_wgrad(N_.ptr(xd), N_.ptr(dzd), N_.ptr(dW), n, H, W, N_.stream()), "stem wgrad")
+    wst = torch.empty(int(N_.lib().fdet_mbt_taps_ws_bytes(16, 0)) // 4 + 4, device="cuda")
+    N_.check(N_.lib().fdet_mbt_stem_wgrad(N_.ptr(xd), N_.ptr(dzd), N_.ptr(dW), N_.ptr(wst), wst.numel() * 4, n, H, W, N_.stream()),
+             "stem wgrad")
     close(dW, w.grad, 1e-5, "stem wgrad")
 
 
