@@ -324,7 +324,17 @@ size_t fdet_ps_bytes(int N, int C, int H, int W);
 size_t fdet_ps_image0_offset(int N, int C, int H, int W);
 int fdet_ps_from_f32(const float* x, void* ps, int N, int C, int H, int W, void* stream);
 int fdet_ps_to_f32(const void* ps, float* x, int N, int C, int H, int W, void* stream);
-/* 3x3 convs on PS tensors (Cout == 64, Cin % 16 == 0, maps of 15..62 columns); wpk: forward / backward panels of
+/* Column strips (round 4; config 3's 320 / 160 / 80-column maps, models/Resnet.py:30-40): an even map wider than 63 columns is
+ * kept as S = fdet_ps_strips(W) strips of <= 62 columns, each a PS image of its own whose edge slots hold the neighbour
+ * strip's column.  Every fdet_*_ps entry point takes the FULL width and plans the strips itself; the caller's part is
+ *   fdet_ps_halo_exchange(zero_only = 0)  after a producer that writes real elements only (a conv epilogue,
+ *                                         fdet_pool_route_bwd_ps) and before a 3x3 conv reads the tensor;
+ *   fdet_ps_halo_exchange(zero_only = 1)  before the tensor is the dz operand of fdet_conv3x3_wgrad_ps_batched (a halo slot
+ *                                         is not a position of its strip) when its halo slots may hold columns;
+ * fdet_ps_from_f32 writes the halos itself.  Both are no-ops on plain (<= 63-column) tensors. */
+int fdet_ps_strips(int W);
+int fdet_ps_halo_exchange(void* ps, int N, int C, int H, int W, int zero_only, int hi_only, void* stream);
+/* 3x3 convs on PS tensors (Cout == 64, Cin % 16 == 0, maps of 15..62 columns, or wider even maps as column strips); wpk: forward / backward panels of
  * fdet_pack_conv3x3_weights_bf16x3.  Same arithmetic as fdet_conv3x3_fwd_bf16x3 / fdet_conv3x3_dgrad_bf16x3
  * (models/PoolResnet.py:33-36 and its autograd):
  *   fwd      : y_ps  = LeakyReLU(conv(x_ps) + bias)

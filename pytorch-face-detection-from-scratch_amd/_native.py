@@ -78,6 +78,8 @@ SIGNATURES = {
     "fdet_ps_image0_offset": (_SZ, [_I, _I, _I, _I]),
     "fdet_ps_from_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fdet_ps_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fdet_ps_strips": (_I, [_I]),
+    "fdet_ps_halo_exchange": (_I, [_P, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_conv3x3_ps_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_ps_dgrad_act": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_conv3x3_ps_fwd_pool": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

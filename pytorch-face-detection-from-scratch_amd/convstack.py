@@ -160,6 +160,7 @@ class ConvStack:
         # and their gradients live as bf16 hi|lo units, staged by LDS-DMA (FDET_PS=0: the fp32-I/O kernels of round 2)
         self.ps = self.pool_fusion and geo.filters == 64 and os.environ.get("FDET_PS", "1") != "0"
         self._ps_pool: Dict[tuple, list] = {}
+        self.ps_strips = self.ps and os.environ.get("FDET_PS_STRIPS", "1") != "0"
         # precision16 (FDET_PRECISION=bf16 or set_precision("bf16")): the PS kernels run ONE bf16 MFMA pass on the hi planes
         # (bf16 activations and weights, fp32 accumulation / epilogues / master weights) -- the arithmetic of the reference's
         # Trainer(precision=16), train_model.py:50, with bf16 as the 16-bit type.  Only where the PS path runs (64 channels);
@@ -238,13 +239,22 @@ class ConvStack:
 
     # ------------------------------------------------------------------ PS buffers
     def _ps_block(self, k: int) -> bool:
-        """Block k runs on pre-split activations: a pooled block whose even map is 30..62 columns wide."""
+        """Block k runs on pre-split activations: a pooled block whose even map is 30..62 columns wide, or wider and kept
+        as column strips (csrc/fdet_ps.h; FDET_PS_STRIPS=0: the round-2 kernels for wide maps)."""
         if not self.ps or k >= len(self.lv):
             return False
         hk, pool = self.lv[k]
+        if pool != 2 or hk % 2 or hk < 30:
+            return False
         # (the batch-dependent limits of run_ps: 32-bit byte offsets of the fp32 tensors the pooled modes touch)
-        return pool == 2 and hk % 2 == 0 and 30 <= hk <= 62 and self._fused_pool(hk, self._cur_N) and \
-            self._cur_N * self.geo.filters * hk * hk * 4 < 2 ** 31
+        if self._cur_N * self.geo.filters * hk * hk * 4 >= 2 ** 31:
+            return False
+        if hk > 62:
+            return self.ps_strips and psm.strips_of(hk)[0] > 1 and psm.conv3x3_wgrad_ps_ws_bytes(1, self._cur_N, self.geo.filters, hk, hk) > 0
+        return self._fused_pool(hk, self._cur_N)
+
+    def _strips(self, hk: int) -> bool:
+        return hk > 62
 
     def _ps_chain(self, k: int) -> bool:
         """The chain run starting at block k keeps its per-block tensors in PS (fdet_block_chain_*_ps) and its weight
@@ -301,14 +311,15 @@ class ConvStack:
             self._ps_pool.clear()
             self._cur_N = N
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
-        h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev) if not (self._ps_block(0) and self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)) else None
+        stem_ps = self._ps_block(0) and not self._strips(self.h0) and self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)
+        h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev) if not stem_ps else None
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
         stem_bytes = 4.0 * N * (g.in_ch * g.H * g.W + F_ * self.h0 * self.h0)
         scope = _PsScope(self._ps_pool)
         h_ps = None
         stem_x3 = self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)
         with self._t("stem_fwd", N, self.h0, stem_flops, stem_bytes):
-            if self._ps_block(0) and stem_x3:
+            if stem_ps:
                 h, h_ps = None, self._ps_take(scope, N, F_, self.h0, self.h0, dev)
                 psm.stem_fwd_ps(x, P["conv1.weight"], P["conv1.bias"], h_ps, g.stem_k, g.stem_s, g.stem_p, p16=self.p16)
             else:
@@ -328,7 +339,9 @@ class ConvStack:
                 a_ps = self._ps_take(scope, N, F_, hk, hk, dev)
                 with self._t("conv3x3_fwd", N, hk, self._conv_flops(N, hk), self._act_bytes(N, hk, 2)):
                     psm.conv3x3_ps_fwd(h_ps, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], a_ps, self.slope, p16=self.p16)
-                nxt = self._ps_block(k + 1) or self._ps_chain(k + 1)
+                    psm.halo_exchange(a_ps, p16=self.p16)      # strips: conv2 (and the weight gradient) read a's edge columns
+                # (a strip level hands its pooled output on as fp32 NCHW; the next level's converter writes its halos)
+                nxt = (self._ps_block(k + 1) or self._ps_chain(k + 1)) and not self._strips(hk)
                 out_ps = self._ps_take(scope, N, F_, hk // 2, hk // 2, dev) if nxt else None
                 out = None if nxt else torch.empty(N, F_, hk // 2, hk // 2, dtype=F32, device=dev)
                 route = psm.route8_like(N, F_, hk, hk, dev) if save else None
@@ -592,20 +605,37 @@ class ConvStack:
                     xin = psm.PsTensor.from_f32(xin.to(F32).contiguous(), out=self._ps_take(scope, N, F_, hk, hk, dev))
                 if not isinstance(a, psm.PsTensor):
                     a = psm.PsTensor.from_f32(a.to(F32).contiguous(), out=self._ps_take(scope, N, F_, hk, hk, dev))
+                strips = self._strips(hk)
                 if c.dim() == 4:                           # routing bytes in NCHW -> channel-innermost
+                    if strips:
+                        raise ValueError("routing bytes of a strip level are per strip (ps.route8_shape)")
                     c = c.view(N, F_ // 8, 8, hk // 2, hk // 2).permute(0, 1, 3, 4, 2).contiguous()
                 fl = self._conv_flops(N, hk)
+
+                def wgrad_now(x_, dz_, nm_):
+                    # strips: the weight gradient wants ZERO halo slots in dz (a halo is not a position of its strip), the
+                    # data-gradient conv behind it the neighbour columns -- so each layer's weight gradient runs right
+                    # here, between the two halo passes, instead of in the level's batched launch
+                    psm.halo_exchange(dz_, zero_only=True, p16=self.p16)
+                    pending_ps.append((x_, dz_, nm_))
+                    flush_ps(hk)
+                    psm.halo_exchange(dz_, p16=self.p16)
                 dz2 = self._ps_take(scope, N, F_, hk, hk, dev)
                 with self._t("pool_route_bwd", N, hk, 0.0, self._act_bytes(N, hk, 1 + 0.25 + 1 / 16)):
                     psm.pool_route_bwd_ps(dout, c, sc, dz2, self.slope, p16=self.p16)
+                if strips:
+                    wgrad_now(a, dz2, name + ".conv2")
                 dz1 = self._ps_take(scope, N, F_, hk, hk, dev)
                 with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
                     psm.conv3x3_ps_dgrad_act(dz2, self._wpk[name + ".conv2.b"], a, dz1, self.slope, p16=self.p16)
+                if strips:
+                    wgrad_now(xin, dz1, name + ".conv1")
                 dx = torch.empty(N, F_, hk, hk, dtype=F32, device=dev)
                 with self._t("conv3x3_dgrad_unpool", N, hk, fl, self._act_bytes(N, hk, 2 + 0.25 + 1 / 16)):
                     psm.conv3x3_ps_dgrad_unpool(dz1, self._wpk[name + ".conv1.b"], dout, c, dx, self.slope, p16=self.p16)
-                pending_ps.append((a, dz2, name + ".conv2"))
-                pending_ps.append((xin, dz1, name + ".conv1"))
+                if not strips:
+                    pending_ps.append((a, dz2, name + ".conv2"))
+                    pending_ps.append((xin, dz1, name + ".conv1"))
                 dout = dx
                 if k == 0 or self.lv[k - 1][0] != hk or not self._ps_block(k - 1):
                     flush_ps(hk)

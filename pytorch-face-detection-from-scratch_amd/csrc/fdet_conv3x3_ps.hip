@@ -54,6 +54,11 @@ struct PsConvArgs {
   const unsigned char* route_in;
   float* dx_f32;             // DGRAD_ADDPOOL: dx, fp32 NCHW
   int Hp, Wp, HPp, WPp, plane_p, img_p;
+  // column strips (fdet_ps.h): N counts strip-images (index = s * Nimg + n); the last strip (index >= last0) holds Wlast
+  // columns; the fp32 NCHW tensors of the pooled modes are addressed by image with rows of Wf (pooled: Wpf) columns, strip s
+  // starting at column s * xo.  Without strips: Nimg = N, last0 = 0, Wlast = W, Wf = W, Wpf = Wp.
+  int Nimg, last0, Wlast, Wf, Wpf, xo;
+  unsigned magic_nimg;
   int N, H, W, HP;
   int nch, ntiles;
   int plane_i, img_i, plane_o, img_o;
@@ -247,7 +252,7 @@ k_conv3x3_ps(const PsConvArgs p) {
       const int col_ = q_ & (WP - 1);                                                              \
       const int v_ = (T) * R + (q_ >> WPL);                                                        \
       const int nn_ = (int)__umulhi((unsigned)v_, p.magic_hp), y_ = v_ - nn_ * HP;                 \
-      okn[n_] = nn_ < p.N && y_ < p.H && col_ < p.W;                                               \
+      okn[n_] = nn_ < p.N && y_ < p.H && col_ < (nn_ >= p.last0 ? p.Wlast : p.W);                  \
       ob[n_] = nn_ * p.img_o + y_ * WP + col_ + 1;                                                 \
     }                                                                                              \
   }
@@ -340,7 +345,7 @@ k_conv3x3_ps(const PsConvArgs p) {
             const int m_ = it_ >> 4, gp_ = (it_ >> 3) & 1, ab_ = (it_ >> 2) & 1, i_ = it_ & 3;     \
             const int arg_ = (int)((rkp[m_][gp_][ab_] >> (8 * i_ + 4)) & 3u);                      \
             const float gv_ = dgp[m_][gp_][ab_][i_];                                               \
-            const int so_ = (32 * m_ + 16 * gp_ + 8 * ab_ + i_) * p.H * p.W * 4;                   \
+            const int so_ = (32 * m_ + 16 * gp_ + 8 * ab_ + i_) * p.H * p.Wf * 4;                  \
             _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                     \
               float z0_, z1_;                                                                      \
               ps_acc_read(PREV[WOVEN ? m_ : 0][WOVEN ? 2 * r_ : 0], 8 * gp_ + 4 * ab_ + i_, z0_);  \
@@ -348,7 +353,7 @@ k_conv3x3_ps(const PsConvArgs p) {
               z0_ += arg_ == 2 * r_ ? gv_ : 0.f;                                                   \
               z1_ += arg_ == 2 * r_ + 1 ? gv_ : 0.f;                                               \
               __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(unsigned, z0_), __builtin_bit_cast(unsigned, z1_)}, prs, sto, \
-                                                    so_ + r_ * p.W * 4, 0);                        \
+                                                    so_ + r_ * p.Wf * 4, 0);                       \
             }                                                                                      \
           }                                                                                        \
         } else {                                                                                   \
@@ -383,8 +388,8 @@ k_conv3x3_ps(const PsConvArgs p) {
   }
   // ---- pooled-block epilogues (POOLM mapping): geometry of this lane's window in tile T
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(MODE == PSE_FWD_POOL ? (void*)p.pool_ps : (void*)p.dx_f32, 0,
-      MODE == PSE_FWD_POOL ? (int)((size_t)p.N * p.img_p * 16) : (int)((size_t)p.N * 64 * p.H * p.W * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(p.pool_f32, 0, (int)((size_t)p.N * 64 * p.Hp * p.Wp * 4), 0x00020000);
+      MODE == PSE_FWD_POOL ? (int)((size_t)p.N * p.img_p * 16) : (int)((size_t)p.Nimg * 64 * p.H * p.Wf * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(p.pool_f32, 0, (int)((size_t)p.Nimg * 64 * p.Hp * p.Wpf * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(p.route_out, 0, (int)((size_t)p.N * 64 * p.Hp * p.Wp), 0x00020000);
   const int pool_cnt = MODE == PSE_FWD_POOL ? 4 * ((P16 ? 1 : 2) * (p.pool_ps != nullptr) + (p.route_out != nullptr) + 8 * (p.pool_f32 != nullptr)) : 63;
 #define PS_WIN(T)                                                                                  \
@@ -392,7 +397,10 @@ k_conv3x3_ps(const PsConvArgs p) {
     const int v_ = (T) * R + rb_;                                                                  \
     const int nn = (int)__umulhi((unsigned)v_, p.magic_hp), y = v_ - nn * HP;                      \
     const int xp = WP == 64 ? l31 : (l31 & 15), yp = y >> 1;                                       \
-    const bool okw = nn < p.N && y < p.H && 2 * xp < p.W;
+    const bool okw = nn < p.N && y < p.H && 2 * xp < (nn >= p.last0 ? p.Wlast : p.W);              \
+    /* image and pooled column in the fp32 NCHW tensors (strips: nn = s * Nimg + ni) */            \
+    const int si = p.last0 == 0 ? 0 : (p.Nimg == 1 ? nn : (int)__umulhi((unsigned)nn, p.magic_nimg)); \
+    const int ni = nn - si * p.Nimg, xg = si * (p.xo >> 1) + xp;
   // DGRAD_ADDPOOL, woven: the pooled gradient and routing bytes of the PREVIOUS tile's windows (40 loads, always issued:
   // a lane without a window reads element 0) and the byte offset of its first dx element (out of range without a window)
   float dgp[2][2][2][4];
@@ -411,8 +419,8 @@ k_conv3x3_ps(const PsConvArgs p) {
 #define PS_POOLPREF(T)                                                                             \
   {                                                                                                \
     PS_WIN(T)                                                                                      \
-    const int HWp = p.Hp * p.Wp;                                                                   \
-    const int pbase = okw ? (nn * 64 * p.Hp + yp) * p.Wp + xp : 0;                                 \
+    const int HWp = p.Hp * p.Wpf, HWr = p.Hp * p.Wp;                                               \
+    const int pbase = okw ? (ni * 64 * p.Hp + yp) * p.Wpf + xg : 0;                                \
     const int rbase = okw ? (nn * 8 * p.Hp + yp) * p.Wp + xp : 0;                                  \
     _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
       _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                             \
@@ -422,9 +430,9 @@ k_conv3x3_ps(const PsConvArgs p) {
             const float v_ = p.dout[pbase + (8 * G + 4 * half + i) * HWp];                         \
             dgp[m][gp][ab][i] = okw ? v_ : 0.f;                                                    \
           }                                                                                        \
-          rkp[m][gp][ab] = *reinterpret_cast<const unsigned*>(p.route_in + (size_t)(rbase + G * HWp) * 8 + 4 * half); \
+          rkp[m][gp][ab] = *reinterpret_cast<const unsigned*>(p.route_in + (size_t)(rbase + G * HWr) * 8 + 4 * half); \
         }                                                                                          \
-    sto = okw ? (unsigned)(((nn * 64 + 4 * half) * p.H + y) * p.W + 2 * xp) * 4u : 0x80000000u;    \
+    sto = okw ? (unsigned)(((ni * 64 + 4 * half) * p.H + y) * p.Wf + 2 * xg) * 4u : 0x80000000u;   \
   }
   // maxpool2x2(lrelu(acc + bias) * scale + skip) -> pooled PS / fp32 NCHW, routing bytes.  Every load first; stores are
   // buffer stores with the validity in the offset (exactly pool_cnt per wave, counted by the next tile's first wait).
@@ -446,8 +454,8 @@ k_conv3x3_ps(const PsConvArgs p) {
         }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
           const int ch = 32 * m + 16 * gp + 4 * half + i;                                          \
-          scv[m][gp][0][i] = (p.scale && okw) ? p.scale[nn * 64 + ch] : 1.f;                       \
-          scv[m][gp][1][i] = (p.scale && okw) ? p.scale[nn * 64 + ch + 8] : 1.f;                   \
+          scv[m][gp][0][i] = (p.scale && okw) ? p.scale[ni * 64 + ch] : 1.f;                       \
+          scv[m][gp][1][i] = (p.scale && okw) ? p.scale[ni * 64 + ch + 8] : 1.f;                   \
         }                                                                                          \
       }                                                                                            \
     /* values first, then ONE section per output whose branch is uniform for the whole kernel: the number of stores */ \
@@ -479,10 +487,10 @@ k_conv3x3_ps(const PsConvArgs p) {
     if (p.pool_f32) {   /* this lane's own 8 channels: 32m + 16gp + 8ab + 4half + i */              \
       _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
         _Pragma("unroll") for (int gp = 0; gp < 2; ++gp) {                                         \
-          const unsigned off = okw ? (unsigned)(((nn * 64 + 32 * m + 16 * gp + 4 * half) * p.Hp + yp) * p.Wp + xp) * 4u : 0x80000000u; \
+          const unsigned off = okw ? (unsigned)(((ni * 64 + 32 * m + 16 * gp + 4 * half) * p.Hp + yp) * p.Wpf + xg) * 4u : 0x80000000u; \
           _Pragma("unroll") for (int jj = 0; jj < 8; ++jj)                                         \
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pvs[m][gp][jj >> 2][jj & 3]), frs, off, \
-                                                  (8 * (jj >> 2) + (jj & 3)) * p.Hp * p.Wp * 4, 0); \
+                                                  (8 * (jj >> 2) + (jj & 3)) * p.Hp * p.Wpf * 4, 0); \
         }                                                                                          \
     }                                                                                              \
     /* half exchange: lanes 0-31 keep group 2gp (channels 0-3 own, 4-7 from the upper half), lanes 32-63 group 2gp+1 */ \
@@ -525,8 +533,8 @@ k_conv3x3_ps(const PsConvArgs p) {
     PS_WIN(T)                                                                                      \
     float dg[2][2][2][4];                                                                          \
     unsigned rk[2][2][2];                                                                          \
-    const int HWp = p.Hp * p.Wp;                                                                   \
-    const int pbase = okw ? (nn * 64 * p.Hp + yp) * p.Wp + xp : 0;                                 \
+    const int HWp = p.Hp * p.Wpf;                                                                  \
+    const int pbase = okw ? (ni * 64 * p.Hp + yp) * p.Wpf + xg : 0;                                \
     _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
       _Pragma("unroll") for (int gp = 0; gp < 2; ++gp)                                             \
         _Pragma("unroll") for (int ab = 0; ab < 2; ++ab) {                                         \
@@ -547,7 +555,7 @@ k_conv3x3_ps(const PsConvArgs p) {
               ps_acc_read(ACC[m][2 * r + 1], 8 * gp + 4 * ab + i, z1);                             \
               z0 += arg == 2 * r ? gv : 0.f;                                                       \
               z1 += arg == 2 * r + 1 ? gv : 0.f;                                                   \
-              const unsigned off = okw ? (unsigned)(((nn * 64 + ch) * p.H + y + r) * p.W + 2 * xp) * 4u : 0x80000000u; \
+              const unsigned off = okw ? (unsigned)(((ni * 64 + ch) * p.H + y + r) * p.Wf + 2 * xg) * 4u : 0x80000000u; \
               __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(unsigned, z0), __builtin_bit_cast(unsigned, z1)}, prs, off, 0, 0); \
             }                                                                                      \
           }                                                                                        \
@@ -693,10 +701,15 @@ struct PsPoolIO {
 int run_ps(int mode, const void* x, const void* wpk, const float* bias, const void* aux, void* y, const PsPoolIO& io, int N,
            int Cin, int Cout, int H, int W, float slope, hipStream_t st, bool p16 = false) {
   PsGeo gi, go, gp;
+  PsStrips sp, spo;
   const bool pooled = mode == PSE_FWD_POOL || mode == PSE_DGRAD_ADDPOOL;
   FDET_REQUIRE(x && wpk && (y || pooled), "conv3x3_ps: null pointer");
   FDET_REQUIRE(Cout == 64 && Cin % 16 == 0 && Cin >= 32, "conv3x3_ps: Cout must be 64 and Cin a multiple of 16 (Cin=%d Cout=%d)", Cin, Cout);
-  FDET_REQUIRE(ps_geo(N, Cin, H, W, gi) && ps_geo(N, Cout, H, W, go) && gi.WP >= 32 && W + 2 <= gi.WP, "conv3x3_ps: unsupported map %dx%d (W + 2 <= 32 or 64 slots)", H, W);
+  // maps wider than 62 columns run as column strips (fdet_ps.h): N, W below are those of the strip-images
+  FDET_REQUIRE(ps_geo_strips(N, Cin, H, W, gi, sp) && ps_geo_strips(N, Cout, H, W, go, spo) && gi.WP >= 32 && sp.Ws + 2 <= gi.WP,
+               "conv3x3_ps: unsupported map %dx%d (W + 2 <= 32 or 64 slots, or an even width in strips)", H, W);
+  const int Nimg = N, Wfull = W;
+  N = gi.N; W = sp.Ws;
   FDET_REQUIRE(slope >= 0.f && slope <= 1.f, "conv3x3_ps: slope must be in [0, 1]");
   PsConvArgs p;
   p.x = reinterpret_cast<const bf16x8*>(x);
@@ -709,9 +722,12 @@ int run_ps(int mode, const void* x, const void* wpk, const float* bias, const vo
   p.scale = io.scale; p.pool_ps = reinterpret_cast<bf16x8*>(io.pool_ps); p.pool_f32 = io.pool_f32; p.route_out = io.route_out;
   p.dout = io.dout; p.route_in = io.route_in; p.dx_f32 = io.dx_f32;
   p.Hp = H / 2; p.Wp = W / 2; p.HPp = p.WPp = p.plane_p = p.img_p = 0;
+  p.Nimg = Nimg; p.last0 = sp.S > 1 ? (sp.S - 1) * Nimg : 0; p.Wlast = sp.Wlast; p.Wf = Wfull; p.Wpf = Wfull / 2; p.xo = sp.Ws;
+  p.magic_nimg = Nimg > 1 ? magic_of(Nimg) : 0u;
   if (pooled) {
     FDET_REQUIRE(!(H & 1) && !(W & 1) && Cin == 64, "conv3x3_ps (pooled block): even map and 64 channels required (H=%d W=%d Cin=%d)", H, W, Cin);
-    FDET_REQUIRE((size_t)N * 64 * H * W * 4 < ((size_t)1 << 31), "conv3x3_ps (pooled block): tensor too large for 32-bit offsets");
+    FDET_REQUIRE((size_t)Nimg * 64 * H * Wfull * 4 < ((size_t)1 << 31), "conv3x3_ps (pooled block): tensor too large for 32-bit offsets");
+    FDET_REQUIRE(sp.S == 1 || !io.pool_ps, "conv3x3_ps_fwd_pool: a strip map writes its pooled output as fp32 NCHW (pool_f32)");
     if (mode == PSE_FWD_POOL && io.pool_ps) {
       FDET_REQUIRE(ps_geo(N, 64, H / 2, W / 2, gp), "conv3x3_ps_fwd_pool: the pooled map %dx%d has no PS layout", H / 2, W / 2);
       p.HPp = gp.HP; p.WPp = gp.WP; p.plane_p = gp.plane; p.img_p = gp.img;

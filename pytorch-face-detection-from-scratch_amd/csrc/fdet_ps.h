@@ -44,6 +44,26 @@ inline bool ps_geo(int N, int C, int H, int W, PsGeo& g) {
   return true;
 }
 
+// Column strips (round 4): a map wider than 62 columns is kept as S strips of Ws <= 62 columns, every strip a PS "image" of
+// its own (64 slots per row; strip-image index = s * Nimg + n, strip-major), so that the 64-slot kernels serve rows of any
+// width.  Slot 0 / slot Ws + 1 of an interior strip edge hold the NEIGHBOUR strip's edge column (a real halo, written by
+// fdet_ps_from_f32 or fdet_ps_halo_exchange) instead of a zero; the last strip holds Wlast <= Ws columns, the rest stays zero.
+struct PsStrips {
+  int S, Nimg, Ws, Wf, Wlast;
+};
+
+inline bool ps_geo_strips(int N, int C, int H, int W, PsGeo& g, PsStrips& st) {
+  st.S = 1; st.Nimg = N; st.Ws = W; st.Wf = W; st.Wlast = W;
+  if (W <= 63) return ps_geo(N, C, H, W, g);
+  if (W & 1) return false;
+  st.S = (W + 61) / 62;
+  st.Ws = ((W + st.S - 1) / st.S + 1) & ~1;
+  st.Wlast = W - (st.S - 1) * st.Ws;
+  if (st.Wlast <= 0 || st.Ws > 62 || (long long)N * st.S >= (1 << 20)) return false;
+  if (!ps_geo(N * st.S, C, H, st.Ws, g)) return false;
+  return g.WP == 64;
+}
+
 }  // namespace fdet
 
 // hi/lo split of four floats into packed bf16 pairs (RNE, lo = bf16(x - float(hi))): hi[0] = {x0,x1}, hi[1] = {x2,x3}

@@ -335,9 +335,10 @@ int wg_num_cus() {
 }
 
 int wg_plan(int L, int N, int H, int W, PsGeo& g, int& nslab, int& lpw) {
-  if (!ps_geo(N, 64, H, W, g) || L < 1 || L > WG_MAXL) return 0;
+  PsStrips sp;                                           // wide maps: column strips (fdet_ps.h); g.N counts strip-images
+  if (!ps_geo_strips(N, 64, H, W, g, sp) || L < 1 || L > WG_MAXL) return 0;
   const int lpi = g.HP * g.WP / 64;
-  const long nlines = (long)N * lpi;
+  const long nlines = (long)g.N * lpi;
   if (nlines + 2 * lpi >= (1 << 20)) return 0;
   nslab = std::max(1, std::min((int)nlines, wg_num_cus() / L));
   lpw = (int)((nlines + nslab - 1) / nslab);
@@ -379,7 +380,7 @@ int wgrad_ps_run(const void* const* h_x, const void* const* h_dz, float* const* 
   a.plane = g.plane; a.img = g.img;
   a.lpi = g.HP * g.WP / 64;
   a.real_lpi = (H * g.WP + 63) / 64;
-  a.nlines = N * a.lpi;
+  a.nlines = g.N * a.lpi;                                // (strips: the dz halo slots must be ZERO, fdet_ps_halo_exchange(zero_only))
   a.nslab = nslab; a.lpw = lpw;
   a.magic_lpi = magic_of(a.lpi);
   const size_t lds = (size_t)WG_LDS_UNITS * 16;

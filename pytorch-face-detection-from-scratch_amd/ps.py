@@ -16,14 +16,26 @@ from ._native import FdetError, check, lib, ptr, stream
 F32 = torch.float32
 
 
+def strips_of(W: int):
+    """(S, Ws): column strips of a map of width W (csrc/fdet_ps.h) -- (1, W) for maps of up to 63 columns, (0, 0) when the
+    width has no layout (odd and wider than 63)."""
+    S = int(lib().fdet_ps_strips(int(W)))
+    if S <= 1:
+        return S, (W if S == 1 else 0)
+    return S, ((W + S - 1) // S + 1) & ~1
+
+
 class PsTensor:
-    """bf16 hi|lo planes of a (N,C,H,W) feature map, 8 channels innermost, zero halos (see csrc/fdet_ps.h)."""
+    """bf16 hi|lo planes of a (N,C,H,W) feature map, 8 channels innermost, zero halos (see csrc/fdet_ps.h).  Maps wider than
+    63 columns are kept as column strips (`strips` > 1): the C-ABI plans them from the full width, the caller's part is
+    `halo_exchange` (below)."""
 
     def __init__(self, N: int, C: int, H: int, W: int, device):
         nbytes = int(lib().fdet_ps_bytes(N, C, H, W))
         if nbytes == 0:
-            raise FdetError(f"PsTensor: unsupported shape ({N},{C},{H},{W}) (C % 8 == 0, W <= 62 required)")
+            raise FdetError(f"PsTensor: unsupported shape ({N},{C},{H},{W}) (C % 8 == 0; W <= 63 or even)")
         self.shape = (N, C, H, W)
+        self.strips = strips_of(W)[0]
         self.buf = torch.zeros(nbytes // 4, dtype=F32, device=device)        # zeroed ONCE
         self._off = int(lib().fdet_ps_image0_offset(N, C, H, W))
 
@@ -54,6 +66,22 @@ class PsTensor:
             raise ValueError("PsTensor.to_f32: output shape mismatch")
         check(lib().fdet_ps_to_f32(self.data, ptr(y), N, C, H, W, stream()), "fdet_ps_to_f32")
         return y
+
+
+def halo_exchange(t: PsTensor, zero_only: bool = False, p16: bool = False) -> None:
+    """Strip tensors (a no-op otherwise): copy the neighbour strips' edge columns into the halo slots (after a producer that
+    wrote real elements only, before a 3x3 conv reads `t`), or -- zero_only -- clear them (before `t` is the dz operand of the
+    weight gradient)."""
+    if t.strips <= 1:
+        return
+    N, C, H, W = t.shape
+    check(lib().fdet_ps_halo_exchange(t.data, N, C, H, W, int(zero_only), int(p16), stream()), "fdet_ps_halo_exchange")
+
+
+def route8_shape(N: int, C: int, H: int, W: int):
+    """Shape of the routing bytes of a pooled block whose conv maps are (H, W): per strip-image, channel-innermost."""
+    S, Ws = strips_of(W)
+    return (N * S, C // 8, H // 2, Ws // 2, 8)
 
 
 def _same(a: PsTensor, shape, name):
@@ -111,7 +139,7 @@ def conv3x3_wgrad_ps_batched(xs, dzs, dWs, dbs, ws: torch.Tensor, p16: bool = Fa
 
 def route8_like(N: int, C: int, H: int, W: int, device) -> torch.Tensor:
     """Routing bytes of a pooled block whose conv maps are (H, W): uint8 [N, C/8, H/2, W/2, 8]."""
-    return torch.empty(N, C // 8, H // 2, W // 2, 8, dtype=torch.uint8, device=device)
+    return torch.empty(*route8_shape(N, C, H, W), dtype=torch.uint8, device=device)
 
 
 def conv3x3_ps_fwd_pool(x: PsTensor, wpk, bias, skip: PsTensor, drop_scale, pool_ps: PsTensor = None,
@@ -124,8 +152,10 @@ def conv3x3_ps_fwd_pool(x: PsTensor, wpk, bias, skip: PsTensor, drop_scale, pool
         _same(pool_ps, (N, cout, H // 2, W // 2), "conv3x3_ps_fwd_pool: pool_ps")
     if pool_f32 is not None and tuple(pool_f32.shape) != (N, cout, H // 2, W // 2):
         raise ValueError("conv3x3_ps_fwd_pool: pool_f32 shape")
-    if route8 is not None and tuple(route8.shape) != (N, cout // 8, H // 2, W // 2, 8):
+    if route8 is not None and tuple(route8.shape) != route8_shape(N, cout, H, W):
         raise ValueError("conv3x3_ps_fwd_pool: route8 shape")
+    if pool_ps is not None and x.strips > 1:
+        raise ValueError("conv3x3_ps_fwd_pool: a strip map writes its pooled output as fp32 NCHW (pool_f32)")
     if drop_scale is not None and tuple(drop_scale.shape) != (N, cout):
         raise ValueError("conv3x3_ps_fwd_pool: drop_scale shape")
     if wpk.numel() != cout * cin * 9:
@@ -140,7 +170,7 @@ def pool_route_bwd_ps(dout_pooled: torch.Tensor, route8: torch.Tensor, drop_scal
                       p16: bool = False) -> None:
     """dz2 (PS) = unpool(dout_pooled) * drop_scale * lrelu'(c) from the routing bytes."""
     N, C, H, W = dz2.shape
-    if tuple(dout_pooled.shape) != (N, C, H // 2, W // 2) or tuple(route8.shape) != (N, C // 8, H // 2, W // 2, 8):
+    if tuple(dout_pooled.shape) != (N, C, H // 2, W // 2) or tuple(route8.shape) != route8_shape(N, C, H, W):
         raise ValueError("pool_route_bwd_ps: shapes")
     check(_fn("fdet_pool_route_bwd_ps", p16)(ptr(dout_pooled), ptr(route8, torch.uint8), ptr(drop_scale), dz2.data, N, C, H, W,
                                              float(slope), stream()), "fdet_pool_route_bwd_ps")
@@ -152,7 +182,7 @@ def conv3x3_ps_dgrad_unpool(dz: PsTensor, wpk_bwd, dout_pooled: torch.Tensor, ro
     N, cout, H, W = dz.shape
     cin = dx.shape[1]
     if tuple(dx.shape) != (N, cin, H, W) or tuple(dout_pooled.shape) != (N, cin, H // 2, W // 2) or \
-            tuple(route8.shape) != (N, cin // 8, H // 2, W // 2, 8):
+            tuple(route8.shape) != route8_shape(N, cin, H, W):
         raise ValueError("conv3x3_ps_dgrad_unpool: shapes")
     if wpk_bwd.numel() != cout * cin * 9:
         raise ValueError("conv3x3_ps_dgrad_unpool: packed weight size does not match (Cout,Cin)")
