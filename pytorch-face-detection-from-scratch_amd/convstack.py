@@ -311,7 +311,11 @@ class ConvStack:
             self._ps_pool.clear()
             self._cur_N = N
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
-        stem_ps = self._ps_block(0) and not self._strips(self.h0) and self.x3 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)
+        # the stem writes the first block's PS input itself: the PoolResnet stem (k10 s8 p2, plain layout) or the Resnet stem
+        # (k3 s2 p1, column strips included)
+        stem_ps = self._ps_block(0) and self.x3 and \
+            ((not self._strips(self.h0) and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)) or
+             hp.stem_k3_fwd_ps_supported(g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p))
         h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev) if not stem_ps else None
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
         stem_bytes = 4.0 * N * (g.in_ch * g.H * g.W + F_ * self.h0 * self.h0)
@@ -691,7 +695,8 @@ class ConvStack:
         ws = self._workspace("stem", hp.stem_ws_bytes(N, g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p), dev)
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
         with self._t("stem_wgrad", N, self.h0, stem_flops, 4.0 * N * (g.in_ch * g.H * g.W + F_ * self.h0 * self.h0)):
-            stem_x3 = self.x3 and g.W % 16 == 0 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)
+            stem_x3 = self.x3 and ((g.W % 16 == 0 and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)) or
+                                   hp.stem_k3_wgrad_x3_supported(g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p))
             hp.stem_wgrad(x, dout, G["conv1.weight"], G["conv1.bias"], ws, g.stem_k, g.stem_s, g.stem_p, x3=stem_x3,
                           p16=self.p16 and stem_x3 and 48 < self.h0 <= 60)
         join()

@@ -21,6 +21,12 @@ int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int
 int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16);
 int stem_dma_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16);
 int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st, bool p16);
+// fdet_stem_k3.hip: the Resnet stem (k3 s2 p1) on the matrix cores / with a PS (column-strip) output
+bool stem3_wgrad_ok(int Cin, int F, int H, int W, int k, int stride, int pad);
+size_t stem3_wgrad_ws_floats(int N, int F, int H, int W);
+int stem3_wgrad(const float* x, const float* dz, float* dW, float* db, float* ws, size_t ws_floats, int N, int F, int H, int W, hipStream_t st);
+bool stem3_fwd_ps_ok(int Cin, int F, int H, int W, int k, int stride, int pad);
+int stem3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16);
 }
 
 namespace {
@@ -327,6 +333,7 @@ extern "C" size_t fdet_stem_ws_bytes(int N, int Cin, int F, int H, int W, int k,
   if (!stem_plan(N, Cin, F, H, W, k, stride, pad, p)) return 0;
   size_t fl = p.ws_floats;
   if (stem_mfma_ok(Cin, F, H, W, k, stride, pad)) fl = std::max(fl, stem_mfma_ws_floats(N, F, H, W));
+  if (stem3_wgrad_ok(Cin, F, H, W, k, stride, pad)) fl = std::max(fl, stem3_wgrad_ws_floats(N, F, H, W));
   return fl * 4;
 }
 
@@ -366,7 +373,9 @@ extern "C" int fdet_stem_fwd_bf16x3(const float* x, const float* w, const float*
 // the PoolResnet stem with a pre-split (PS) output: y_ps = image-0 pointer of a PS tensor (N, 64, Ho, Wo)
 extern "C" int fdet_stem_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int Cin, int F, int H,
                                 int W, int k, int stride, int pad, void* stream) {
-  FDET_REQUIRE(x && w && bias && y_ps && N > 0 && F == 64, "stem_fwd_ps: bad arguments (F must be 64)");
+  FDET_REQUIRE(x && w && bias && y_ps && N > 0, "stem_fwd_ps: bad arguments");
+  if (stem3_fwd_ps_ok(Cin, F, H, W, k, stride, pad)) return stem3_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, false);
+  FDET_REQUIRE(F == 64, "stem_fwd_ps: F must be 64");
   FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad),
                "stem_fwd_ps: only the PoolResnet stem (3ch k10 s8 p2, W%%4==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
                Cin, k, stride, pad, W);
@@ -378,7 +387,9 @@ extern "C" int fdet_stem_fwd_ps(const float* x, const float* w, const float* bia
 // precision16: one MFMA pass on bf16(x) x bf16(w), hi plane of the PS output only (see fdet_conv3x3_ps_fwd_p16)
 extern "C" int fdet_stem_fwd_ps_p16(const float* x, const float* w, const float* bias, void* y_ps, int N, int Cin, int F, int H,
                                     int W, int k, int stride, int pad, void* stream) {
-  FDET_REQUIRE(x && w && bias && y_ps && N > 0 && F == 64, "stem_fwd_ps_p16: bad arguments (F must be 64)");
+  FDET_REQUIRE(x && w && bias && y_ps && N > 0, "stem_fwd_ps_p16: bad arguments");
+  if (stem3_fwd_ps_ok(Cin, F, H, W, k, stride, pad)) return stem3_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, true);
+  FDET_REQUIRE(F == 64, "stem_fwd_ps_p16: F must be 64");
   FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad),
                "stem_fwd_ps_p16: only the PoolResnet stem (3ch k10 s8 p2, W%%4==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
                Cin, k, stride, pad, W);
@@ -390,6 +401,8 @@ extern "C" int fdet_stem_fwd_ps_p16(const float* x, const float* w, const float*
 extern "C" int fdet_stem_wgrad_bf16x3(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,
                                       int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream) {
   FDET_REQUIRE(x && dy && dW && db && ws && N > 0 && F > 0, "stem_wgrad_bf16x3: bad arguments");
+  if (stem3_wgrad_ok(Cin, F, H, W, k, stride, pad))       // the Resnet stem (k3 s2 p1), fdet_stem_k3.hip
+    return stem3_wgrad(x, dy, dW, db, (float*)ws, ws_bytes / 4, N, F, H, W, (hipStream_t)stream);
   FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad) && W % 16 == 0,
                "stem_wgrad_bf16x3: only the PoolResnet stem (3ch k10 s8 p2, W%%16==0, W<=512) is built; got Cin=%d k=%d s=%d p=%d W=%d",
                Cin, k, stride, pad, W);

@@ -647,6 +647,16 @@ def stem_fwd(x, w, bias, y, ws, k, stride, pad, x3: bool = False):
              Nn, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_fwd")
 
 
+def stem_k3_wgrad_x3_supported(cin, F_, H, W, k, stride, pad) -> bool:
+    """The Resnet stem (3 channels, k3 s2 p1) has a matrix-core (bf16x3) weight gradient for this shape (fdet_stem_k3.hip)."""
+    Wo = (W + 2 * pad - k) // stride + 1
+    return cin == 3 and (k, stride, pad) == (3, 2, 1) and F_ % 8 == 0 and H % 2 == 0 and W % 4 == 0 and Wo % 16 == 0 and Wo <= 320
+
+
+def stem_k3_fwd_ps_supported(cin, F_, H, W, k, stride, pad) -> bool:
+    return cin == 3 and (k, stride, pad) == (3, 2, 1) and F_ % 8 == 0 and H % 2 == 0 and W % 2 == 0
+
+
 def stem_wgrad(x, dy, dW, db, ws, k, stride, pad, x3: bool = False, p16: bool = False):
     Nn, cin, H, W = x.shape
     F_ = dW.shape[0]

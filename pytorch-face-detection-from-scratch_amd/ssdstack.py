@@ -203,7 +203,8 @@ class SSDStack:
             hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], ci, dx, add=addt, slope=self.slope, x3=True)
             dtrunk = dx
         ws = self._workspace("stem", hp.stem_ws_bytes(N, 3, self.filters, self.size, self.size, 3, 2, 1), dev)
-        hp.stem_wgrad(x, dtrunk, G["input_normalizer.weight"], G["input_normalizer.bias"], ws, 3, 2, 1)
+        hp.stem_wgrad(x, dtrunk, G["input_normalizer.weight"], G["input_normalizer.bias"], ws, 3, 2, 1,
+                      x3=hp.stem_k3_wgrad_x3_supported(3, self.filters, self.size, self.size, 3, 2, 1))   # bf16x3 like every other layer of the stack
 
 
 class SSDStackFn(torch.autograd.Function):

@@ -133,7 +133,7 @@ def test_block_tail(hp, pool):
 
 
 @pytest.mark.parametrize("cfg", [(2, 64, 480, 10, 8, 2), (3, 8, 480, 10, 8, 2), (2, 32, 240, 3, 2, 1),
-                                 (1, 64, 640, 3, 2, 1)])
+                                 (1, 64, 640, 3, 2, 1), (3, 16, 480, 3, 2, 1), (2, 64, 96, 3, 2, 1)])
 def test_stem(hp, cfg):
     N, Fo, size, k, s, p = cfg
     g = torch.Generator().manual_seed(Fo + size)
@@ -161,6 +161,25 @@ def test_stem(hp, cfg):
         hp.stem_wgrad(x.cuda(), dy.cuda(), dW3, db3, ws, k, s, p, x3=True)
         close(dW3, wr.grad)
         close(db3, br.grad)
+    if hp.stem_k3_wgrad_x3_supported(3, Fo, size, size, k, s, p):      # the Resnet stem on the matrix cores (fdet_stem_k3.hip)
+        dW3 = torch.full((Fo, 3, k, k), float("nan"), device="cuda"); db3 = torch.full((Fo,), float("nan"), device="cuda")
+        hp.stem_wgrad(x.cuda(), dy.cuda(), dW3, db3, ws, k, s, p, x3=True)
+        close(dW3, wr.grad)
+        close(db3, br.grad)
+        dW4 = torch.empty_like(dW3); db4 = torch.empty_like(db3)
+        hp.stem_wgrad(x.cuda(), dy.cuda(), dW4, db4, ws, k, s, p, x3=True)
+        assert torch.equal(dW3, dW4) and torch.equal(db3, db4)          # fixed-order reduction: bit-reproducible
+    if hp.stem_k3_fwd_ps_supported(3, Fo, size, size, k, s, p):         # ... and its forward with a PS (column-strip) output
+        from fdet_amd import ps
+        yp = ps.PsTensor(N, Fo, Ho, Ho, "cuda")
+        ps.stem_fwd_ps(x.cuda(), w.cuda(), b.cuda(), yp, k, s, p)
+        close(yp.to_f32(), F.conv2d(x, w, b, stride=s, padding=p))
+        before = yp.buf.view(torch.int32).clone()                        # the halo slots it wrote are what the exchange writes
+        ps.halo_exchange(yp)
+        assert torch.equal(yp.buf.view(torch.int32), before)
+        if yp.strips > 1:
+            ps.halo_exchange(yp, zero_only=True)
+            assert not torch.equal(yp.buf.view(torch.int32), before)
 
 
 @pytest.mark.parametrize("cfg", [(3, 64, 15, 6, 0), (2, 8, 15, 6, 0), (2, 32, 15, 3, 1), (2, 64, 20, 3, 1), (1, 128, 15, 6, 0)])
