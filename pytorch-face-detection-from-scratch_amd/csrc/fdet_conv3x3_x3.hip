@@ -102,6 +102,9 @@ int run_x3(ConvArgs a, hipStream_t st) {
       if (a.act && !a.skip) a.mode = EPI_DGRAD_ACT;
       else if (!a.act && a.skip) a.mode = EPI_DGRAD_ADD;
     }
+  } else if (a.Cout % 16 == 0 && a.dgrad) {                // the data-gradient epilogues guard the upper half tile themselves
+    if (a.act && !a.skip) a.mode = EPI_DGRAD_ACT;
+    else if (!a.act && a.skip) a.mode = EPI_DGRAD_ADD;
   }
   // vector width of the global accesses: rows of W floats must keep VW-float alignment
   auto aligned = [](const void* q, size_t b) { return q == nullptr || ((uintptr_t)q % b) == 0; };

@@ -62,6 +62,14 @@ class SSDStack:
         self._key = None
         self._ws: Dict[str, torch.Tensor] = {}
         self.slope = 0.2
+        self._pending: list = []                           # same-shape weight gradients awaiting one batched launch
+        self.timer = None                                  # convstack.KernelTimer: per-launch HIP events (bench.py's config-4 table)
+
+    def _t(self, kind: str, hk: int, ci: int, co: int):
+        if self.timer is None:
+            from .convstack import _NOSPAN
+            return _NOSPAN
+        return self.timer.span(f"{kind}@{hk}x{hk}:{ci}->{co}", 0.0, 0.0)
 
     # ------------------------------------------------------------------ weights
     def _pack(self, key: str, w3: torch.Tensor):
@@ -111,7 +119,8 @@ class SSDStack:
         h0 = self.size // 2
         ws = self._workspace("stem", hp.stem_ws_bytes(N, 3, f, self.size, self.size, 3, 2, 1), dev)
         h = torch.empty(N, f, h0, h0, dtype=F32, device=dev)
-        hp.stem_fwd(x, P["input_normalizer.weight"], P["input_normalizer.bias"], h, ws, 3, 2, 1)
+        with self._t("stem_fwd", h0, 3, f):
+            hp.stem_fwd(x, P["input_normalizer.weight"], P["input_normalizer.bias"], h, ws, 3, 2, 1)
         y = torch.empty(N, self.P, 5, dtype=F32, device=dev)
         saved = {"x": x, "blocks": [], "masks": masks, "heads": {}} if save else None
         for name, ci, co, pool, head in self.specs:
@@ -121,26 +130,32 @@ class SSDStack:
                 skip = h
             else:
                 skip = torch.empty(N, co, hk, hk, dtype=F32, device=dev)
-                hp.pointwise_fwd(h, self._wpk[name + ".skip.f"], P[name + ".pointwise_conv_skip.bias"], skip)
+                with self._t("skip1x1_fwd", hk, ci, co):
+                    hp.pointwise_fwd(h, self._wpk[name + ".skip.f"], P[name + ".pointwise_conv_skip.bias"], skip)
             a = torch.empty(N, co, hk, hk, dtype=F32, device=dev)
-            hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], co, y_full=a, slope=self.slope, x3=True)
+            with self._t("conv3x3_fwd", hk, ci, co):
+                hp.conv3x3_fwd(h, self._wpk[name + ".conv1.f"], P[name + ".conv1.bias"], co, y_full=a, slope=self.slope, x3=True)
             ho = hk // 2 if pool else hk
             out = torch.empty(N, co, ho, ho, dtype=F32, device=dev)
             c = torch.empty_like(a) if (pool or save) else None
             if pool:
-                hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], co, y_full=c, slope=self.slope, x3=True)
-                hp.block_tail_fwd(c, skip, sc, out, 2)
+                with self._t("conv3x3_fwd", hk, co, co):
+                    hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], co, y_full=c, slope=self.slope, x3=True)
+                with self._t("tail_fwd", hk, co, co):
+                    hp.block_tail_fwd(c, skip, sc, out, 2)
             else:
-                hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], co, y_full=c, skip=skip,
-                               drop_scale=sc, y_out=out, slope=self.slope, x3=True)
+                with self._t("conv3x3_fwd", hk, co, co):
+                    hp.conv3x3_fwd(a, self._wpk[name + ".conv2.f"], P[name + ".conv2.bias"], co, y_full=c, skip=skip,
+                                   drop_scale=sc, y_out=out, slope=self.slope, x3=True)
             if save:
                 saved["blocks"].append((h, skip, a, c))
             h = out
             if head >= 0:
                 hn = f"extracting_layers.{head}.0"
                 z = torch.empty(N, 5, ho, ho, dtype=F32, device=dev)       # Linear(C,5) at every position
-                hp.pointwise_fwd(h, self._wpk[hn + ".f"], P[hn + ".bias"], z)
-                hp.ssd_head_pack_fwd(z, PATCH_SIZES[head], self.starts[head], y)
+                with self._t("head", ho, co, 5):
+                    hp.pointwise_fwd(h, self._wpk[hn + ".f"], P[hn + ".bias"], z)
+                    hp.ssd_head_pack_fwd(z, PATCH_SIZES[head], self.starts[head], y)
                 if save:
                     saved["heads"][head] = h
         if save:
@@ -148,15 +163,39 @@ class SSDStack:
         return y, saved
 
     # ------------------------------------------------------------------ backward
-    def _wgrad(self, xin, dz, dev):
+    def _wgrad(self, xin, dz, dW, db, dev):
+        """dW / db (the caller's gradient tensors, written in place) of one 3x3 conv.  Same-shape layers (the six 2F -> 2F
+        blocks at 60x60: twelve weight gradients of ~45 us each) are collected and go out in ONE batched launch."""
         N, ci, H, W = xin.shape
         co = dz.shape[1]
-        dW = torch.empty(co, ci, 3, 3, dtype=F32, device=dev)
-        db = torch.empty(co, dtype=F32, device=dev)
+        key = (N, ci, co, H, W)
+        if self._pending and self._pending[0][0] != key:
+            self._flush_wgrads(dev)
+        if hp.conv3x3_wgrad_batched_ws_bytes(2, N, ci, co, H, W) > 0:
+            self._pending.append((key, xin, dz, dW, db))
+            if len(self._pending) == 16:
+                self._flush_wgrads(dev)
+            return
         x3 = hp.wgrad_x3_supported(N, ci, co, H, W)
         ws = self._workspace("wgrad", hp.conv3x3_wgrad_ws_bytes(N, ci, co, H, W), dev)
-        hp.conv3x3_wgrad(xin, dz, dW, db, ws, x3=x3)
-        return dW, db
+        with self._t("conv3x3_wgrad", H, ci, co):
+            hp.conv3x3_wgrad(xin, dz, dW, db, ws, x3=x3)
+
+    def _flush_wgrads(self, dev):
+        grp, self._pending = self._pending, []
+        if not grp:
+            return
+        N, ci, co, H, W = grp[0][0]
+        nb = hp.conv3x3_wgrad_batched_ws_bytes(len(grp), N, ci, co, H, W) if len(grp) > 1 else 0
+        if nb == 0:                                        # a single layer, or no batched plan for this many
+            ws = self._workspace("wgrad", hp.conv3x3_wgrad_ws_bytes(N, ci, co, H, W), dev)
+            for _, xin, dz, dW, db in grp:
+                with self._t("conv3x3_wgrad", H, ci, co):
+                    hp.conv3x3_wgrad(xin, dz, dW, db, ws, x3=hp.wgrad_x3_supported(N, ci, co, H, W))
+            return
+        ws = self._workspace("wgrad_batched", nb, dev)
+        with self._t(f"conv3x3_wgrad(x{len(grp)})", H, ci, co):
+            hp.conv3x3_wgrad_batched([g_[1] for g_ in grp], [g_[2] for g_ in grp], [g_[3] for g_ in grp], [g_[4] for g_ in grp], ws)
 
     def backward(self, saved, dy, P, G) -> None:
         """dy = d loss / d y (N,4774,5); writes the gradient of every parameter into G[name]."""
@@ -164,6 +203,7 @@ class SSDStack:
         N, dev = x.shape[0], x.device
         dy = dy.to(F32).contiguous()
         dtrunk = None
+        self._pending = []
         for bi in reversed(range(len(self.specs))):
             name, ci, co, pool, head = self.specs[bi]
             hin, skip, a, c = saved["blocks"][bi]
@@ -173,38 +213,43 @@ class SSDStack:
                 hn = f"extracting_layers.{head}.0"
                 hout = saved["heads"][head]
                 dz = torch.empty(N, 5, ho, ho, dtype=F32, device=dev)
-                hp.ssd_head_pack_bwd(dy, y, PATCH_SIZES[head], self.starts[head], dz)
-                hp.pointwise_wgrad(hout, dz, G[hn + ".weight"], G[hn + ".bias"])
-                dout = torch.empty_like(hout)
-                hp.pointwise_dgrad(dz, self._wpk[hn + ".b"], dout, add=dtrunk)
+                with self._t("head_bwd", ho, co, 5):
+                    hp.ssd_head_pack_bwd(dy, y, PATCH_SIZES[head], self.starts[head], dz)
+                    hp.pointwise_wgrad(hout, dz, G[hn + ".weight"], G[hn + ".bias"])
+                    dout = torch.empty_like(hout)
+                    hp.pointwise_dgrad(dz, self._wpk[hn + ".b"], dout, add=dtrunk)
             else:
                 dout = dtrunk
             sc = masks[name] if masks is not None else None
             dz2 = torch.empty_like(a)
-            if pool:
-                de = torch.empty_like(a)
-                hp.block_tail_bwd(dout, c, skip, sc, dz2, de, 2, self.slope)
-            else:
-                de = dout
-                hp.block_tail_bwd(dout, c, None, sc, dz2, None, 1, self.slope)
-            dW, db = self._wgrad(a, dz2, dev)
-            G[name + ".conv2.weight"].copy_(dW); G[name + ".conv2.bias"].copy_(db)
+            with self._t("tail_bwd", hk, co, co):
+                if pool:
+                    de = torch.empty_like(a)
+                    hp.block_tail_bwd(dout, c, skip, sc, dz2, de, 2, self.slope)
+                else:
+                    de = dout
+                    hp.block_tail_bwd(dout, c, None, sc, dz2, None, 1, self.slope)
+            self._wgrad(a, dz2, G[name + ".conv2.weight"], G[name + ".conv2.bias"], dev)
             dz1 = torch.empty_like(a)
-            hp.conv3x3_dgrad(dz2, self._wpk[name + ".conv2.b"], co, dz1, act=a, slope=self.slope, x3=True)
-            dW, db = self._wgrad(hin, dz1, dev)
-            G[name + ".conv1.weight"].copy_(dW); G[name + ".conv1.bias"].copy_(db)
+            with self._t("conv3x3_dgrad", hk, co, co):
+                hp.conv3x3_dgrad(dz2, self._wpk[name + ".conv2.b"], co, dz1, act=a, slope=self.slope, x3=True)
+            self._wgrad(hin, dz1, G[name + ".conv1.weight"], G[name + ".conv1.bias"], dev)
             if ci == co:
                 addt = de
             else:
-                hp.pointwise_wgrad(hin, de, G[name + ".pointwise_conv_skip.weight"], G[name + ".pointwise_conv_skip.bias"])
-                addt = torch.empty_like(hin)
-                hp.pointwise_dgrad(de, self._wpk[name + ".skip.b"], addt)
+                with self._t("skip1x1_bwd", hk, ci, co):
+                    hp.pointwise_wgrad(hin, de, G[name + ".pointwise_conv_skip.weight"], G[name + ".pointwise_conv_skip.bias"])
+                    addt = torch.empty_like(hin)
+                    hp.pointwise_dgrad(de, self._wpk[name + ".skip.b"], addt)
             dx = torch.empty_like(hin)
-            hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], ci, dx, add=addt, slope=self.slope, x3=True)
+            with self._t("conv3x3_dgrad", hk, co, ci):
+                hp.conv3x3_dgrad(dz1, self._wpk[name + ".conv1.b"], ci, dx, add=addt, slope=self.slope, x3=True)
             dtrunk = dx
+        self._flush_wgrads(dev)
         ws = self._workspace("stem", hp.stem_ws_bytes(N, 3, self.filters, self.size, self.size, 3, 2, 1), dev)
-        hp.stem_wgrad(x, dtrunk, G["input_normalizer.weight"], G["input_normalizer.bias"], ws, 3, 2, 1,
-                      x3=hp.stem_k3_wgrad_x3_supported(3, self.filters, self.size, self.size, 3, 2, 1))   # bf16x3 like every other layer of the stack
+        with self._t("stem_wgrad", self.size // 2, 3, self.filters):
+            hp.stem_wgrad(x, dtrunk, G["input_normalizer.weight"], G["input_normalizer.bias"], ws, 3, 2, 1,
+                          x3=hp.stem_k3_wgrad_x3_supported(3, self.filters, self.size, self.size, 3, 2, 1))   # bf16x3 like every other layer of the stack
 
 
 class SSDStackFn(torch.autograd.Function):
