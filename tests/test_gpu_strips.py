@@ -163,3 +163,58 @@ def test_strip_pooled_block(env, shape, train):
     err = ((dx.cpu() - ref_dx).abs() * uniq).max()
     assert float(err) <= 1e-4 * max(1.0, float(ref_dx.abs().max()))
     assert bool(torch.isfinite(dx).all())
+
+
+def _resnet_step(mode: str, strips: bool):
+    """One fused training step of Resnet-64 at 3x256x256 (levels 128 -> 64 -> 32 -> 16 -> 8: strip levels 128 and 64), fixed
+    parameters / masks / batch; returns (loss, y, flat gradient)."""
+    import os
+    import oracle as O
+    from fdet_amd import hotpath as hp
+    from fdet_amd.models import ModelMeta
+    from fdet_amd.models.Resnet import Resnet
+    size, S, B = 256, 8, 3
+    spec = O.resnet_spec(64, (3, size, size), S, 6)
+    P = O.init_params(spec, seed=4)
+    old = os.environ.get("FDET_PS_STRIPS")
+    os.environ["FDET_PS_STRIPS"] = "1" if strips else "0"
+    try:
+        model = Resnet(filters=64, input_shape=(3, size, size), num_of_patches=S, num_of_residual_blocks=6)
+    finally:
+        if old is None:
+            os.environ.pop("FDET_PS_STRIPS", None)
+        else:
+            os.environ["FDET_PS_STRIPS"] = old
+    model.load_state_dict({k: v.clone() for k, v in P.items()})
+    model = model.cuda().train()
+    assert model.engine.ps_strips == strips
+    if mode == "bf16":
+        model.engine.set_precision("bf16")
+    mm = ModelMeta(model=model, lr=1e-4); mm.configure_optimizers()
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(1)).cuda()
+    y = hp.encode_targets(O.synthetic_boxes(B, size, seed=2), (size, size), S)
+    model.set_dropout_masks({k: v.cuda() for k, v in O.make_dropout_masks(spec, B, seed=3).items()})
+    lsum, y_hat, _ = mm.fused_train_step(x, y)
+    return float(lsum), y_hat.clone(), mm.opt.space.grad.clone()
+
+
+def test_strip_levels_equal_the_round2_kernels_end_to_end():
+    """The same training step with the wide levels on column strips (PS kernels) and on the round-2 fp32-I/O kernels: both are
+    fp32-grade bf16x3 paths, so loss, outputs and the flat gradient agree to the usual 1e-4 / L2 5e-3."""
+    la, ya, ga = _resnet_step("bf16x3", True)
+    lb, yb, gb = _resnet_step("bf16x3", False)
+    assert abs(la - lb) <= 1e-4 * max(1.0, abs(lb)), (la, lb)
+    assert float((ya - yb).abs().max()) <= 1e-4
+    rel = float((ga - gb).norm() / gb.norm())
+    assert rel <= 5e-3, rel
+
+
+def test_strip_levels_precision16():
+    """precision16 (one bf16 MFMA pass, hi planes only -- halo exchange included) on the strip levels against the fp32-grade
+    step: bf16-level agreement (tolerances of test_gpu_p16.py)."""
+    la, ya, ga = _resnet_step("bf16x3", True)
+    lb, yb, gb = _resnet_step("bf16", True)
+    assert abs(la - lb) <= 2e-2 * abs(la), (la, lb)
+    assert float((ya - yb).abs().max()) <= 2e-2
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert cos >= 0.995, cos
