@@ -168,7 +168,6 @@ def test_strip_pooled_block(env, shape, train):
 def _resnet_step(mode: str, strips: bool):
     """One fused training step of Resnet-64 at 3x256x256 (levels 128 -> 64 -> 32 -> 16 -> 8: strip levels 128 and 64), fixed
     parameters / masks / batch; returns (loss, y, flat gradient)."""
-    import os
     import oracle as O
     from fdet_amd import hotpath as hp
     from fdet_amd.models import ModelMeta
@@ -176,18 +175,11 @@ def _resnet_step(mode: str, strips: bool):
     size, S, B = 256, 8, 3
     spec = O.resnet_spec(64, (3, size, size), S, 6)
     P = O.init_params(spec, seed=4)
-    old = os.environ.get("FDET_PS_STRIPS")
-    os.environ["FDET_PS_STRIPS"] = "1" if strips else "0"
-    try:
-        model = Resnet(filters=64, input_shape=(3, size, size), num_of_patches=S, num_of_residual_blocks=6)
-    finally:
-        if old is None:
-            os.environ.pop("FDET_PS_STRIPS", None)
-        else:
-            os.environ["FDET_PS_STRIPS"] = old
+    model = Resnet(filters=64, input_shape=(3, size, size), num_of_patches=S, num_of_residual_blocks=6)
     model.load_state_dict({k: v.clone() for k, v in P.items()})
     model = model.cuda().train()
-    assert model.engine.ps_strips == strips
+    assert model.engine.ps and model.engine.ps_strips
+    model.engine.ps_strips = strips                          # (what FDET_PS_STRIPS=0 selects: the round-2 kernels for wide maps)
     if mode == "bf16":
         model.engine.set_precision("bf16")
     mm = ModelMeta(model=model, lr=1e-4); mm.configure_optimizers()
