@@ -288,6 +288,25 @@ def infer_bench(model, size, device, frames=100, warm=20):
             per_batch.append(time.perf_counter() - t0)
         per_batch.sort()
         dtb = per_batch[len(per_batch) // 2]
+        # the same batch as ONE HIP graph (BaseModel.graphed_predict: /255, conv stack, decode + NMS captured once; a replay
+        # is one launch) -- what a serving loop with a fixed batch shape would run
+        graph_ms = None
+        try:
+            gp256 = model.graphed_predict(big)
+            for _ in range(2):
+                gp256(big)
+            torch.cuda.synchronize()
+            gb = []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                gp256(big)
+                torch.cuda.synchronize()
+                gb.append(time.perf_counter() - t0)
+            gb.sort()
+            graph_ms = gb[len(gb) // 2] * 1e3
+            del gp256
+        except Exception:                                    # noqa: BLE001
+            graph_ms = None
         # the same batches in precision16 (engine.set_precision("bf16"): one MFMA pass; maps within ~1e-2 of the fp32-grade
         # ones, so boxes near a threshold may differ -- a second figure, opt-in for serving)
         p16_ms = None
@@ -325,6 +344,7 @@ def infer_bench(model, size, device, frames=100, warm=20):
     return {"demo_path_ms_per_frame": round(dt1 * 1e3, 3), "demo_path_fps": round(1.0 / dt1, 1),
             "demo_path_hipgraph_ms_per_frame": round(dtg * 1e3, 3), "demo_path_hipgraph_fps": round(1.0 / dtg, 1),
             "batched_fps": round(256 / dtb, 1), "batched_ms_per_256": round(dtb * 1e3, 3), "batched_kernels_ms": batched_kernels,
+            "batched_hipgraph": None if graph_ms is None else {"ms_per_256": round(graph_ms, 3), "fps": round(256 / (graph_ms * 1e-3), 1)},
             "batched_precision16": None if p16_ms is None else {"ms_per_256": round(p16_ms, 3), "fps": round(256 / (p16_ms * 1e-3), 1)},
             "batched_ms_min_max": [round(per_batch[0] * 1e3, 3), round(per_batch[-1] * 1e3, 3)],
             "batched_roofline": {"bound": "hbm" if t_hbm >= t_mfma else "mfma", "hbm_floor_ms": round(t_hbm, 3),

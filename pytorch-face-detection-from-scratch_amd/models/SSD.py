@@ -79,8 +79,8 @@ class SSD(nn.Module):
     def non_max_suppression(self, x):
         if len(x.shape) == 3:
             rows, counts = self.reduce_bounding_boxes.forward_batch(x)
-            counts = counts.tolist()
-            return tuple(rows[i, : counts[i]] if counts[i] else torch.empty(0).reshape(0, 5) for i in range(x.shape[0]))
+            from .BaseModel import split_rows
+            return split_rows(rows, counts)
         return self.reduce_bounding_boxes(x)
 
     def single_non_max_suppression(self, x):
