@@ -399,26 +399,48 @@ extern "C" int fdet_step_metrics(const float* gt, const int32_t* gt_counts, cons
 // ======================================================================================
 // u8 -> f32 / 255 -- models/PoolResnet.py:95, datasets/WIDERFace/dataset.py:146
 // ======================================================================================
+// x / 255 for an integer 0 <= x <= 255, bit-identical to the IEEE division: q = x * fl(1/255) is off by an ulp for 126 of the
+// 256 values, one residual correction (two FMAs) makes all 256 exact (tests/test_gpu_detect.py::test_u8_norm_bit_exact covers every value)
+__device__ __forceinline__ float u8_over_255(float x) {
+  const float r = 1.0f / 255.0f;
+  const float q = x * r;
+  const float rem = __builtin_fmaf(-q, 255.0f, x);
+  return __builtin_fmaf(rem, r, q);
+}
+
+// one dword (4 pixels) in, one float4 out per thread and step: a wave reads 256 contiguous bytes and writes 1 KiB contiguous
 __global__ void __launch_bounds__(256)
 k_u8_norm(const uint8_t* __restrict__ in, float* __restrict__ out, size_t n) {
-  const size_t nv = n / 16;
+  const size_t nv = n / 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
-    const uint4 q = reinterpret_cast<const uint4*>(in)[v];
-    const unsigned wv[4] = {q.x, q.y, q.z, q.w};
-    float4* o = reinterpret_cast<float4*>(out) + v * 4;
+  const unsigned* __restrict__ in4 = reinterpret_cast<const unsigned*>(in);
+  float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
+  size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; v + 3 * stride < nv; v += 4 * stride) {           // four independent loads in flight
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = in4[v + k * stride];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float4 f;
-      f.x = (float)(wv[k] & 255u) / 255.0f;
-      f.y = (float)((wv[k] >> 8) & 255u) / 255.0f;
-      f.z = (float)((wv[k] >> 16) & 255u) / 255.0f;
-      f.w = (float)(wv[k] >> 24) / 255.0f;
-      o[k] = f;
+      f.x = u8_over_255((float)(w[k] & 255u));
+      f.y = u8_over_255((float)((w[k] >> 8) & 255u));
+      f.z = u8_over_255((float)((w[k] >> 16) & 255u));
+      f.w = u8_over_255((float)(w[k] >> 24));
+      out4[v + k * stride] = f;
     }
   }
+  for (; v < nv; v += stride) {
+    const unsigned w = in4[v];
+    float4 f;
+    f.x = u8_over_255((float)(w & 255u));
+    f.y = u8_over_255((float)((w >> 8) & 255u));
+    f.z = u8_over_255((float)((w >> 16) & 255u));
+    f.w = u8_over_255((float)(w >> 24));
+    out4[v] = f;
+  }
   if (blockIdx.x == 0)
-    for (size_t t = nv * 16 + threadIdx.x; t < n; t += blockDim.x) out[t] = (float)in[t] / 255.0f;
+    for (size_t t = nv * 4 + threadIdx.x; t < n; t += blockDim.x) out[t] = u8_over_255((float)in[t]);
 }
 
 extern "C" int fdet_u8_to_f32_norm(const uint8_t* in, float* out, size_t n, void* stream) {
@@ -426,7 +448,7 @@ extern "C" int fdet_u8_to_f32_norm(const uint8_t* in, float* out, size_t n, void
   FDET_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "u8_to_f32_norm: pointers must be 16-byte aligned");
   if (n == 0) return FDET_OK;
   size_t blocks = (n / 16 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 4096) blocks = 4096;
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(k_u8_norm, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, n);
   return check_launch("fdet_u8_to_f32_norm");

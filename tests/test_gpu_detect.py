@@ -178,6 +178,8 @@ def test_u8_norm_bit_exact(hp):
     for n in (16 * 7, 3 * 480 * 480 * 2, 1000003):
         x = torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g)
         assert torch.equal(hp.u8_to_f32_norm(x.cuda()).cpu(), x / 255.0)
+    every = torch.arange(256, dtype=torch.uint8).repeat(3)       # every value (the kernel multiplies by 1/255 and corrects)
+    assert torch.equal(hp.u8_to_f32_norm(every.cuda()).cpu(), every / 255.0)
 
 
 def test_adam_vs_oracle(hp):
