@@ -275,7 +275,7 @@ def infer_bench(model, size, device, frames=100, warm=20):
         dtg = (time.perf_counter() - t0) / frames
         big = torch.randint(0, 256, (256, 3, size, size), dtype=torch.uint8, generator=g).to(device)
         for _ in range(2):
-            model.non_max_suppression(model(model._preprocess(big)))
+            model.non_max_suppression(model.forward_frames(big))
         torch.cuda.synchronize()
         # median of 7 individually timed batches (two of five round-4 runs showed 17-20 ms batches in this leg right after the
         # preceding legs' buffers had gone back to the allocator, a third 1.72 ms with identical code: the median keeps one
@@ -283,7 +283,7 @@ def infer_bench(model, size, device, frames=100, warm=20):
         per_batch = []
         for _ in range(7):
             t0 = time.perf_counter()
-            outs = model.non_max_suppression(model(model._preprocess(big)))
+            outs = model.non_max_suppression(model.forward_frames(big))
             torch.cuda.synchronize()
             per_batch.append(time.perf_counter() - t0)
         per_batch.sort()
@@ -313,12 +313,12 @@ def infer_bench(model, size, device, frames=100, warm=20):
         try:
             model.engine.set_precision("bf16")
             for _ in range(2):
-                model.non_max_suppression(model(model._preprocess(big)))
+                model.non_max_suppression(model.forward_frames(big))
             torch.cuda.synchronize()
             pb = []
             for _ in range(5):
                 t0 = time.perf_counter()
-                model.non_max_suppression(model(model._preprocess(big)))
+                model.non_max_suppression(model.forward_frames(big))
                 torch.cuda.synchronize()
                 pb.append(time.perf_counter() - t0)
             pb.sort()
@@ -331,15 +331,17 @@ def infer_bench(model, size, device, frames=100, warm=20):
         # per-kernel table of one batched forward (HIP events on the launch stream)
         from fdet_amd.convstack import KernelTimer
         kt = KernelTimer(); model.engine.timer = kt
-        model(model._preprocess(big))
+        model.forward_frames(big)
         model.engine.timer = None
         batched_kernels = {k: round(v[1], 4) for k, v in sorted(kt.summary().items(), key=lambda kv: -kv[1][1])}
     red.probability_threshold, red.iou_threshold = old_thr
     model.train()
     # roofline of the batched leg (per image): forward 1.0695 GFLOP (x3 bf16 passes), activations 11.81 MB,
-    # plus the uint8 frame read (0.69 MB) and its fp32 image written and read back (2 x 2.76 MB)
+    # plus the uint8 frame read (0.69 MB); the fp32 image (2 x 2.76 MB written and read back until round 4) is no longer part
+    # of the path: forward_frames() hands the uint8 frames to the stem, which divides by 255 in its staging
     t_mfma = 256 * FWD_GFLOP_PER_IMAGE_F64 * 3.0 / (PEAK_BF16_MFMA_TFLOPS * 1e3) * 1e3
-    mb = 256 * (FWD_MB_PER_IMAGE_F64 + 0.69 + 2 * 2.76)
+    fused_u8 = bool(model.engine.u8_frames_ok())
+    mb = 256 * (FWD_MB_PER_IMAGE_F64 + 0.69 + (0.0 if fused_u8 else 2 * 2.76))
     t_hbm = mb / 1e3 / PEAK_HBM_GBS * 1e3
     return {"demo_path_ms_per_frame": round(dt1 * 1e3, 3), "demo_path_fps": round(1.0 / dt1, 1),
             "demo_path_hipgraph_ms_per_frame": round(dtg * 1e3, 3), "demo_path_hipgraph_fps": round(1.0 / dtg, 1),
@@ -351,6 +353,7 @@ def infer_bench(model, size, device, frames=100, warm=20):
                                  "mfma_floor_ms": round(t_mfma, 3), "algorithmic_mb_per_256": round(mb, 1),
                                  "frac_of_max_floor": round(max(t_hbm, t_mfma) / (dtb * 1e3), 4)},
             "demo_path_note": "launch-bound (2 frames: ~20 launches, one count read-back): no roofline quoted",
+            "u8_frames_fused_into_stem": fused_u8,
             "what": "uint8 3x480x480 frames -> /255 -> PoolResnet-medium -> decode -> greedy NMS (thresholds 0.7/0.01 = config 1, "
                     "random-init weights); demo path = 2 stacked frames per call, boxes of image 0 read by the host"}
 

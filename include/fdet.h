@@ -478,6 +478,12 @@ int fdet_pool_route_bwd_ps_p16(const float* dout_pooled, const unsigned char* ro
                                void* dz2_ps, int N, int C, int H, int W, float slope, void* stream);
 int fdet_stem_fwd_ps_p16(const float* x, const float* w, const float* bias, void* y_ps, int N, int Cin, int F, int H,
                          int W, int k, int stride, int pad, void* stream);
+/* Inference: the PoolResnet stem on the uint8 FRAMES themselves: the `x / 255.0` of models/PoolResnet.py:95 (models/BaseModel.py:65)
+ * happens in the stem's staging (a 256-entry table of the bf16 hi | lo parts of p / 255), results identical to
+ * fdet_u8_to_f32_norm + fdet_stem_fwd_ps, and the fp32 image is never written.  frames: [N][3][H][W] uint8, 4-byte aligned,
+ * W % 4 == 0; precision16 != 0: one MFMA pass, hi plane only. */
+int fdet_stem_fwd_ps_u8(const unsigned char* frames, const float* w, const float* bias, void* y_ps, int N, int Cin, int F, int H,
+                        int W, int k, int stride, int pad, int precision16, void* stream);
 int fdet_stem_wgrad_bf16(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,
                          int N, int Cin, int F, int H, int W, int k, int stride, int pad, void* stream);
 int fdet_conv3x3_wgrad_ps_batched_p16(const void* const* h_x, const void* const* h_dz, float* const* h_dW,

@@ -128,6 +128,7 @@ SIGNATURES = {
     "fdet_conv3x3_ps_dgrad_unpool_p16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "fdet_pool_route_bwd_ps_p16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "fdet_stem_fwd_ps_p16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fdet_stem_fwd_ps_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_stem_wgrad_bf16": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fdet_conv3x3_wgrad_ps_batched_p16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "fdet_block_chain_fwd_ps_p16": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

@@ -181,6 +181,13 @@ class ConvStack:
         self.p16 = name == "bf16"
         self._ps_pool.clear()                              # a bf16x3 pass may have left lo planes in pooled buffers
 
+    def u8_frames_ok(self) -> bool:
+        """forward(..., u8_frames=True) is available: the PoolResnet stem writes the first block's PS input itself, so it can
+        read the uint8 frames directly (x / 255 fused into its staging)."""
+        g = self.geo
+        return bool(self.ps and self.x3 and self.lv and 30 <= self.h0 <= 62 and self.lv[0][1] == 2 and g.W % 4 == 0 and
+                    hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p) and g.filters == 64)
+
     def head_loss_fusable(self) -> bool:
         """The fused training head (forward + loss + backward of the head in one launch) covers this geometry."""
         g = self.geo
@@ -291,7 +298,8 @@ class ConvStack:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], masks: Optional[Dict[str, torch.Tensor]] = None,
-                save: bool = False, loss_targets: Optional[torch.Tensor] = None, G: Optional[Dict[str, torch.Tensor]] = None):
+                save: bool = False, loss_targets: Optional[torch.Tensor] = None, G: Optional[Dict[str, torch.Tensor]] = None,
+                u8_frames: bool = False):
         """x (N,C,H,W) f32 on the GPU -> y (N,5,S,S).  masks: per-(n,c) dropout scales
         {"residual_blocks.k": (N,F), "head": (N,F)} or None (eval).  save=True keeps what
         backward needs and returns it as the second value.
@@ -301,7 +309,12 @@ class ConvStack:
         g = self.geo
         if x.dim() != 4 or tuple(x.shape[1:]) != (g.in_ch, g.H, g.W):
             raise ValueError(f"expected input (N,{g.in_ch},{g.H},{g.W}), got {tuple(x.shape)}")
-        if x.dtype != F32 or not x.is_contiguous():
+        if u8_frames:
+            # inference on the uint8 frames themselves: x / 255 happens inside the stem (fdet_stem_fwd_ps_u8)
+            if x.dtype != torch.uint8 or save or not self.u8_frames_ok():
+                raise ValueError("u8_frames: uint8 input, inference only, PoolResnet stem on the pre-split path")
+            x = x.contiguous()
+        elif x.dtype != F32 or not x.is_contiguous():
             x = x.to(F32).contiguous()
         self._ensure_packed(P)
         N, F_, dev = x.shape[0], g.filters, x.device
@@ -316,6 +329,8 @@ class ConvStack:
         stem_ps = self._ps_block(0) and self.x3 and \
             ((not self._strips(self.h0) and hp.stem_x3_supported(g.in_ch, g.W, g.stem_k, g.stem_s, g.stem_p)) or
              hp.stem_k3_fwd_ps_supported(g.in_ch, F_, g.H, g.W, g.stem_k, g.stem_s, g.stem_p))
+        if u8_frames and not stem_ps:                      # (a batch too large for the pre-split path: the separate x / 255)
+            x = hp.u8_to_f32_norm(x)
         h = torch.empty(N, F_, self.h0, self.h0, dtype=F32, device=dev) if not stem_ps else None
         stem_flops = 2.0 * N * F_ * g.in_ch * g.stem_k * g.stem_k * self.h0 * self.h0
         stem_bytes = 4.0 * N * (g.in_ch * g.H * g.W + F_ * self.h0 * self.h0)

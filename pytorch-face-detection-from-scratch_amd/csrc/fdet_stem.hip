@@ -9,6 +9,7 @@
 #include "fdet_common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstdint>
 
 using namespace fdet;
 
@@ -18,7 +19,7 @@ size_t stem_mfma_ws_floats(int N, int F, int H, int W);
 int stem_mfma_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W, hipStream_t st);
 int stem_mfma_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st);
 int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int N, int F, int H, int W, hipStream_t st);   // fdet_stem_x3.hip
-int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16);
+int stem_x3_fwd_ps(const void* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16, bool u8 = false);
 int stem_dma_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16);
 int stem_x3_wgrad(const float* x, const float* dy, float* dW, float* db, float* ws, int N, int F, int H, int W, hipStream_t st, bool p16);
 // fdet_stem_k3.hip: the Resnet stem (k3 s2 p1) on the matrix cores / with a PS (column-strip) output
@@ -396,6 +397,18 @@ extern "C" int fdet_stem_fwd_ps_p16(const float* x, const float* w, const float*
   { const char* e = FDET_ENV_ONCE("FDET_STEM_DMA");
     if (e && e[0] == '1') { const int rc = stem_dma_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, true); if (rc != 1) return rc; } }
   return stem_x3_fwd_ps(x, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, true);
+}
+
+// Inference: the same stem on the uint8 FRAMES themselves -- `x / 255.0` of models/PoolResnet.py:95 (BaseModel.py:65) fused into
+// the staging of the stem (results identical to fdet_u8_to_f32_norm followed by fdet_stem_fwd_ps; the fp32 image is never
+// written).  frames: [N][3][H][W] uint8, W % 4 == 0.  precision16: one MFMA pass, hi plane only.
+extern "C" int fdet_stem_fwd_ps_u8(const unsigned char* frames, const float* w, const float* bias, void* y_ps, int N, int Cin, int F,
+                                   int H, int W, int k, int stride, int pad, int precision16, void* stream) {
+  FDET_REQUIRE(frames && w && bias && y_ps && N > 0 && F == 64, "stem_fwd_ps_u8: bad arguments (F must be 64)");
+  FDET_REQUIRE(stem_mfma_ok(Cin, F, H, W, k, stride, pad) && ((uintptr_t)frames % 4) == 0,
+               "stem_fwd_ps_u8: only the PoolResnet stem (3ch k10 s8 p2, W%%4==0, W<=512) on 4-byte aligned frames; got Cin=%d k=%d s=%d p=%d W=%d",
+               Cin, k, stride, pad, W);
+  return stem_x3_fwd_ps(frames, w, bias, y_ps, N, F, H, W, (hipStream_t)stream, precision16 != 0, true);
 }
 
 extern "C" int fdet_stem_wgrad_bf16x3(const float* x, const float* dy, float* dW, float* db, void* ws, size_t ws_bytes,

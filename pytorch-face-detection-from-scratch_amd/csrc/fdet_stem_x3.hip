@@ -164,6 +164,16 @@ template <bool AG>
 __device__ __forceinline__ void sx_apass(f32x4& d) {
   if constexpr (AG) asm volatile("" : "+a"(d)); else asm volatile("" : "+v"(d));
 }
+// the same for ONE dword (four uint8 pixels; U8 instantiations)
+template <bool AG>
+__device__ __forceinline__ void sx_aload1(unsigned& d, unsigned off, const u32x4s& rs) {
+  if constexpr (AG) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=a"(d) : "v"(off), "s"(rs));
+  else asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(d) : "v"(off), "s"(rs));
+}
+template <bool AG>
+__device__ __forceinline__ void sx_apass1(unsigned& d) {
+  if constexpr (AG) asm volatile("" : "+a"(d)); else asm volatile("" : "+v"(d));
+}
 __device__ __forceinline__ void sx_split_pair(float f0, float f1, unsigned& hi, unsigned& lo) {
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -183,10 +193,15 @@ __device__ __forceinline__ unsigned sx_hi_pair(float f0, float f1) {
 
 // P16 (precision16, PS output only): one MFMA pass on bf16(x) x bf16(w); the lo halves are neither computed nor staged and
 // only the hi plane of the output is written.
-template <bool PSO, bool P16 = false>
+// U8 (inference, PS output only): the input is the uint8 frame itself -- `x / 255` (models/PoolResnet.py:95) happens in the
+// staging job through a 256-entry table of (bf16 hi | bf16 lo) pairs of p / 255 in LDS, i.e. the values the fp32 path splits
+// out of fdet_u8_to_f32_norm's output, bit for bit; a slot loads one dword (4 pixels) instead of a float4, and the fp32 image
+// (2.76 MB per frame written and read back) never exists.
+template <bool PSO, bool P16 = false, bool U8 = false>
 __global__ void __launch_bounds__(256, 1)
 k_stem_fwd_x3_pipe(const StemX3Args a) {
   static_assert(PSO || !P16, "precision16 stem: PS output only");
+  static_assert(PSO || !U8, "uint8 stem: PS output only");
   constexpr int NST = PSO ? (P16 ? 2 : 4) : 16;        // output stores per row (they sit in the memory queue of the counted waits)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = NROW * RL * 2;                   // bf16 elements per tile: hi rows, then lo rows
@@ -203,6 +218,13 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
     for (int t = tid; t < 2 * TILE * 2 / 16; t += 256) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < 64) sbias[tid] = cob * 64 + tid < a.F ? a.bias[cob * 64 + tid] : 0.f;
   }
+  unsigned* const lut = reinterpret_cast<unsigned*>(smem + 2 * TILE * 2 + 256);   // U8: [256] (hi | lo << 16) of p / 255
+  if (U8) {
+    const float f = (float)tid / 255.0f;                 // IEEE division, as torch's `x / 255.0`
+    unsigned h_, l_;
+    sx_split_pair(f, 0.f, h_, l_);
+    lut[tid] = (h_ & 0xffffu) | (l_ << 16);
+  }
   bf16x8 ah[NROW], al[NROW];
 #pragma unroll
   for (int rr = 0; rr < NROW; ++rr) {
@@ -216,11 +238,12 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
     }
   }
   const unsigned long long pa = (unsigned long long)a.x;
-  const u32x4s rx = {(unsigned)pa, (unsigned)(pa >> 32), (unsigned)(a.N * CIN * a.H * a.W) * 4u, 0x00020000u};
+  const u32x4s rx = {(unsigned)pa, (unsigned)(pa >> 32), (unsigned)(a.N * CIN * a.H * a.W) * (U8 ? 1u : 4u), 0x00020000u};
   // staging slot s of a thread: input row rr = (s*256 + tid) >> 7, float4 j = (s*256 + tid) & 127 -> rr = 2s + (tid >> 7)
   const int j4 = tid & 127, rsub = tid >> 7;
   const bool lane_ok = j4 < jmax;
-  f32x4 p0[NSLOT], p1[NSLOT];
+  f32x4 p0[U8 ? 1 : NSLOT], p1[U8 ? 1 : NSLOT];
+  unsigned q0[U8 ? NSLOT : 1], q1[U8 ? NSLOT : 1];           // U8: one dword (four pixels) per slot
   // load slot SL of output row (RN, ROY) into register SL of set S; ROY < 0: nothing (zeros)
 #define SXP_LOAD1(S, SL, RN, ROY)                                                               \
   {                                                                                             \
@@ -228,13 +251,15 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
     const int ci = irow_ / KS, ky = irow_ - ci * KS;                                            \
     const int iy = (ROY) * ST - PD + ky;                                                        \
     const bool ok = lane_ok & ((ROY) >= 0) & (iy >= 0) & (iy < a.H);                           \
-    const unsigned off = ((unsigned)(((RN) * CIN + ci) * a.H + iy) * a.W + j4 * 4) * 4u;       \
-    sx_aload<S == 0>(p##S[SL], ok ? off : 0x80000000u, rx);                                     \
+    const unsigned off = ((unsigned)(((RN) * CIN + ci) * a.H + iy) * a.W + j4 * 4) * (U8 ? 1u : 4u); \
+    if constexpr (U8) sx_aload1<S == 0>(q##S[SL], ok ? off : 0x80000000u, rx);                  \
+    else sx_aload<S == 0>(p##S[SL], ok ? off : 0x80000000u, rx);                                \
   }
 #define SXP_WAIT(S, NKEEP)                                                                      \
   {                                                                                             \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKEEP));                                           \
-    sx_static_for<NSLOT>(SX_LAMBDA(s_) { sx_apass<S == 0>(p##S[s_]); });                        \
+    if constexpr (U8) { sx_static_for<NSLOT>(SX_LAMBDA(s_) { sx_apass1<S == 0>(q##S[s_]); }); } \
+    else { sx_static_for<NSLOT>(SX_LAMBDA(s_) { sx_apass<S == 0>(p##S[s_]); }); }               \
   }
   // lanes past the row's width hold zeros and write them into the row's (zero) right pad
 #define SXP_JOB(S, SL, TB)                                                                      \
@@ -242,7 +267,16 @@ k_stem_fwd_x3_pipe(const StemX3Args a) {
     __bf16* d_ = base + (TB) * TILE + (2 * (SL) + rsub) * RL + 4 + 4 * j4;                      \
     unsigned h0, l0, h1, l1;                                                                    \
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));                               \
-    if (P16) {                                                                                  \
+    if constexpr (U8) {                                                                         \
+      const unsigned w_ = q##S[SL];                  /* a lane past the row's width loaded 0: table entry 0 is (0, 0) */ \
+      const unsigned t0 = lut[w_ & 255u], t1 = lut[(w_ >> 8) & 255u], t2 = lut[(w_ >> 16) & 255u], t3 = lut[w_ >> 24]; \
+      h0 = __builtin_amdgcn_perm(t1, t0, 0x05040100u); h1 = __builtin_amdgcn_perm(t3, t2, 0x05040100u);       \
+      *reinterpret_cast<u32x2_t*>(d_) = u32x2_t{h0, h1};                                        \
+      if (!P16) {                                                                               \
+        l0 = __builtin_amdgcn_perm(t1, t0, 0x07060302u); l1 = __builtin_amdgcn_perm(t3, t2, 0x07060302u);     \
+        *reinterpret_cast<u32x2_t*>(d_ + NROW * RL) = u32x2_t{l0, l1};                          \
+      }                                                                                         \
+    } else if (P16) {                                                                           \
       h0 = sx_hi_pair(p##S[SL][0], p##S[SL][1]); h1 = sx_hi_pair(p##S[SL][2], p##S[SL][3]);     \
       *reinterpret_cast<u32x2_t*>(d_) = u32x2_t{h0, h1};                                        \
     } else {                                                                                    \
@@ -818,9 +852,11 @@ int stem_x3_fwd(const float* x, const float* w, const float* bias, float* y, int
 }
 
 // the same forward with a pre-split (PS) output: y_ps = image-0 pointer of a PS tensor (N, 64, Ho, Wo)
-int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16) {
+int stem_x3_fwd_ps(const void* xin, const float* w, const float* bias, void* y_ps, int N, int F, int H, int W, hipStream_t st, bool p16,
+                   bool u8) {
   StemX3Args a{};
-  a.x = x; a.w = w; a.bias = bias; a.y = reinterpret_cast<float*>(y_ps); a.N = N; a.F = F; a.H = H; a.W = W;
+  a.x = reinterpret_cast<const float*>(xin);               // u8: uint8 frames [N][3][H][W], 4-byte aligned rows (W % 4 == 0)
+  a.w = w; a.bias = bias; a.y = reinterpret_cast<float*>(y_ps); a.N = N; a.F = F; a.H = H; a.W = W;
   a.Ho = (H + 4 - 10) / 8 + 1; a.Wo = (W + 4 - 10) / 8 + 1; a.nrows = N * a.Ho;
   PsGeo g;
   if (F != 64 || !ps_geo(N, F, a.Ho, a.Wo, g) || (size_t)N * CIN * H * W >= ((size_t)1 << 29))
@@ -828,13 +864,17 @@ int stem_x3_fwd_ps(const float* x, const float* w, const float* bias, void* y_ps
   a.ps_hp = g.HP; a.ps_wp = g.WP; a.ps_plane = g.plane; a.ps_img = g.img;
   const int nblk = a.nrows < 256 ? a.nrows : 256;
   const size_t lds = (size_t)NROW * RL * 2 * 2;
-  const void* kern = p16 ? (const void*)k_stem_fwd_x3_pipe<true, true> : (const void*)k_stem_fwd_x3_pipe<true, false>;
-  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds + 256)) != hipSuccess) {
+  const size_t ldsb = 2 * lds + 256 + 1024;                // tiles, bias, the uint8 table
+  const void* kern = u8 ? (p16 ? (const void*)k_stem_fwd_x3_pipe<true, true, true> : (const void*)k_stem_fwd_x3_pipe<true, false, true>)
+                        : (p16 ? (const void*)k_stem_fwd_x3_pipe<true, true> : (const void*)k_stem_fwd_x3_pipe<true, false>);
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) {
     (void)hipGetLastError();
-    return fail(FDET_ELAUNCH, "stem_fwd_ps: cannot reserve %zu bytes of LDS", 2 * lds + 256);
+    return fail(FDET_ELAUNCH, "stem_fwd_ps: cannot reserve %zu bytes of LDS", ldsb);
   }
-  if (p16) hipLaunchKernelGGL((k_stem_fwd_x3_pipe<true, true>), dim3(nblk, 1), dim3(256), 2 * lds + 256, st, a);
-  else hipLaunchKernelGGL((k_stem_fwd_x3_pipe<true, false>), dim3(nblk, 1), dim3(256), 2 * lds + 256, st, a);
+  if (u8 && p16) hipLaunchKernelGGL((k_stem_fwd_x3_pipe<true, true, true>), dim3(nblk, 1), dim3(256), ldsb, st, a);
+  else if (u8) hipLaunchKernelGGL((k_stem_fwd_x3_pipe<true, false, true>), dim3(nblk, 1), dim3(256), ldsb, st, a);
+  else if (p16) hipLaunchKernelGGL((k_stem_fwd_x3_pipe<true, true>), dim3(nblk, 1), dim3(256), ldsb, st, a);
+  else hipLaunchKernelGGL((k_stem_fwd_x3_pipe<true, false>), dim3(nblk, 1), dim3(256), ldsb, st, a);
   return check_launch("fdet_stem_fwd_ps");
 }
 

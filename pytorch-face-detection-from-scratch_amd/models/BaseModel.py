@@ -84,6 +84,23 @@ class BaseModel(nn.Module):
             return hp.u8_to_f32_norm(x)
         return x.float() / 255.0
 
+    def forward_frames(self, x: torch.Tensor) -> torch.Tensor:
+        """`self(self.resize(x) / 255.0)` (models/PoolResnet.py:91-98) for frames -> the (N,5,S,S) maps.  uint8 frames at the
+        model resolution go to the stem AS THEY ARE in inference: the division by 255 is fused into the stem's staging
+        (fdet_stem_fwd_ps_u8; identical results, the fp32 image is never written).  Everything else is
+        `_stack_forward(_preprocess(x))`."""
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        fused = (x.is_cuda and x.dtype == torch.uint8 and tuple(x.shape[-2:]) == tuple(self.input_shape[1:])
+                 and not self.training and getattr(self.engine, "u8_frames_ok", lambda: False)())
+        if fused:
+            names, params = self.named_stack_params()
+            fused = not (torch.is_grad_enabled() and any(p.requires_grad for p in params))
+        if not fused:
+            return self._stack_forward(self._preprocess(x))
+        P = {n: p.detach() for n, p in zip(names, params)}
+        return self.engine.forward(x, P, None, save=False, u8_frames=True)[0]
+
     # -------------------------------------------------------------- HIP-graph replay of the demo path
     def graphed_predict(self, example: torch.Tensor) -> "GraphedPredict":
         """The launch-bound `forward(frames, predict=1)` path (preprocess -> conv stack -> decode -> NMS: ~20 small
@@ -171,7 +188,7 @@ class GraphedPredict:
 
     def _run(self):
         m = self.model
-        y = m._stack_forward(m._preprocess(self.static_in))
+        y = m.forward_frames(self.static_in)
         return m.reduce_bounding_boxes.forward_batch(y)
 
     def __call__(self, frames: torch.Tensor = None):

@@ -141,15 +141,22 @@ class MobilenetV3Backbone(BaseModel):
         with torch.no_grad():
             return self._packed_engine().forward(x)
 
+    def forward_frames(self, x: torch.Tensor) -> torch.Tensor:
+        """`self(self.resize(x) / 255.0)` for frames (BaseModel.forward_frames): uint8 at the model size goes straight to the
+        stem (/255 fused there), everything else through the on-device resize / normalisation."""
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        if not (x.dtype == torch.uint8 and tuple(x.shape[-2:]) == tuple(self.input_shape[1:])):
+            x = self._preprocess(x)
+        return self._stack_forward(x)
+
     def forward(self, x: torch.Tensor, predict: torch.Tensor = torch.tensor(0)):
         if predict == 1:
-            if x.dim() == 3:
-                x = x.unsqueeze(0)
-            if not (x.dtype == torch.uint8 and tuple(x.shape[-2:]) == tuple(self.input_shape[1:])):
-                x = self._preprocess(x)                  # uint8 at the model size goes straight to the stem (/255 fused there)
+            x = self.forward_frames(x)
         elif x.dtype != torch.float32:
             raise TypeError(f"MobilenetV3Backbone.forward: expected float32 in [0,1], got {x.dtype}")
-        x = self._stack_forward(x)
+        else:
+            x = self._stack_forward(x)
         if predict == 1:
             x = self.single_non_max_suppression(x[0])
         return x

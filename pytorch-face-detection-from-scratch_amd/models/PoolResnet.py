@@ -41,8 +41,9 @@ class PoolResnet(BaseModel):
 
     def forward(self, x: torch.Tensor, predict: torch.Tensor = torch.tensor(0)):
         if predict == 1:
-            x = self._preprocess(x)
-        x = self._stack_forward(x)
+            x = self.forward_frames(x)                      # resize / 255 (fused into the stem for uint8 frames) + conv stack
+        else:
+            x = self._stack_forward(x)
         if predict == 1:
             x = self.single_non_max_suppression(x[0])      # image 0 only, as the reference (:103-104)
         return x

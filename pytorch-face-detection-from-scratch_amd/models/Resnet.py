@@ -26,8 +26,9 @@ class Resnet(BaseModel):
 
     def forward(self, x: torch.Tensor, predict: torch.Tensor = torch.tensor(0)):
         if predict == 1:
-            x = self._preprocess(x)
-        x = self._stack_forward(x)
+            x = self.forward_frames(x)                      # resize / 255 (fused into the stem for uint8 frames) + conv stack
+        else:
+            x = self._stack_forward(x)
         if predict == 1:
             x = self.single_non_max_suppression(x[0])
         return x

@@ -192,11 +192,18 @@ def conv3x3_ps_dgrad_unpool(dz: PsTensor, wpk_bwd, dout_pooled: torch.Tensor, ro
 
 def stem_fwd_ps(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, y: PsTensor, k: int, stride: int, pad: int,
                 p16: bool = False) -> None:
-    """PoolResnet stem (3 -> 64 channels, k10 s8 p2) with a PS output."""
+    """PoolResnet stem (3 -> 64 channels, k10 s8 p2) or Resnet stem (k3 s2 p1) with a PS output.  A uint8 `x` (inference:
+    the frames themselves, PoolResnet stem only) is normalised by 255 inside the kernel (fdet_stem_fwd_ps_u8)."""
     N, cin, H, W = x.shape
     F_ = int(w.shape[0])
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     _same(y, (N, F_, Ho, Wo), "stem_fwd_ps: y")
+    if x.dtype == torch.uint8:
+        if not x.is_contiguous():
+            raise ValueError("stem_fwd_ps: uint8 frames must be contiguous")
+        check(lib().fdet_stem_fwd_ps_u8(ptr(x, torch.uint8), ptr(w), ptr(bias), y.data, N, cin, F_, H, W, k, stride, pad, int(p16), stream()),
+              "fdet_stem_fwd_ps_u8")
+        return
     check(_fn("fdet_stem_fwd_ps", p16)(ptr(x), ptr(w), ptr(bias), y.data, N, cin, F_, H, W, k, stride, pad, stream()), "fdet_stem_fwd_ps")
 
 

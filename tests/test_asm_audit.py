@@ -23,8 +23,10 @@ KERNELS = {
     # one-float form is no longer a pipeline (plan_x3 routes those tiny maps to the staged kernel)
     "fdet_wgrad3x3_x3.hip": ["_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi16ELi0E", "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi16ELi1E",
                              "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi4ELi0ELi32ELi1E", "_ZN12_GLOBAL__N_118k_wgrad3x3_x3_pipeILi1ELi0ELi32ELi0E"],
-    "fdet_stem_x3.hip": ["_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb0ELb0E", "_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb1ELb0E",
-                         "_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb1ELb1E", "_ZN12_GLOBAL__N_120k_stem_wgrad_x3_pipeILb0E",
+    # k_stem_fwd_x3_pipe<PSO, P16, U8>: fp32 output, PS output, its precision16 form, and the two uint8-frame forms
+    "fdet_stem_x3.hip": ["_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb0ELb0ELb0E", "_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb1ELb0ELb0E",
+                         "_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb1ELb1ELb0E", "_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb1ELb0ELb1E",
+                         "_ZN12_GLOBAL__N_118k_stem_fwd_x3_pipeILb1ELb1ELb1E", "_ZN12_GLOBAL__N_120k_stem_wgrad_x3_pipeILb0E",
                          "_ZN12_GLOBAL__N_120k_stem_wgrad_x3_pipeILb1E"],
 }
 # The PS kernels issue LDS-DMA from asm (no register destination); their hand-counted waits are audited further down.

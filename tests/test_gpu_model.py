@@ -245,6 +245,33 @@ def test_graphed_predict_equals_eager(fd):
         assert len(both) == 2 and torch.equal(both[0].cpu(), eager.cpu())
 
 
+def test_forward_frames_fuses_the_division_into_the_stem(fd):
+    """forward_frames(uint8 frames) -- what forward(x, predict=1) and the batched serving path run -- hands the frames to the
+    stem as they are (x / 255 in its staging, fdet_stem_fwd_ps_u8): the maps equal _stack_forward(_preprocess(frames)) bit for
+    bit, in both precisions, and a float input / a training-mode model / a model without the pre-split path take the
+    separate normalisation."""
+    from fdet_amd.models.PoolResnet import PoolResnet
+    spec = O.poolresnet_spec(64, (3, 480, 480), 10)
+    P = O.init_params(spec, seed=3)
+    model = PoolResnet(64, (3, 480, 480), 10)
+    model.load_state_dict({k: v.clone() for k, v in P.items()})
+    model = model.cuda().eval()
+    assert model.engine.u8_frames_ok()
+    frames = torch.randint(0, 256, (3, 3, 480, 480), dtype=torch.uint8, generator=torch.Generator().manual_seed(8)).cuda()
+    with torch.no_grad():
+        for mode in ("bf16x3", "bf16"):
+            model.engine.set_precision(mode)
+            two_step = model._stack_forward(model._preprocess(frames))
+            fused = model.forward_frames(frames)
+            assert torch.equal(fused, two_step), mode
+        model.engine.set_precision("bf16x3")
+        assert torch.equal(model.forward_frames(frames.float()), model._stack_forward(frames.float() / 255.0))
+    small = PoolResnet(16, (3, 480, 480), 10).cuda().eval()      # 16 filters: no pre-split path, no fused stem
+    assert not small.engine.u8_frames_ok()
+    with torch.no_grad():
+        assert torch.equal(small.forward_frames(frames), small._stack_forward(small._preprocess(frames)))
+
+
 def _redraw_u8(B, size, seed, checksum):
     x_u8 = torch.randint(0, 256, (B, 3, size, size), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
     assert int(x_u8.long().sum()) == int(checksum)

@@ -277,13 +277,14 @@ def test_p16_equals_fp32_grade_path_within_bf16(golden):
 def test_stem_lds_dma_variant_opt_in():
     """FDET_STEM_DMA=1 selects the LDS-DMA form of the stem forward (csrc/fdet_stem_dma.hip; measured SLOWER than the
     register-staged kernel, kept opt-in: DESIGN.md 2.2d).  The environment switch is read once per process, so the stem tests
-    of both precisions are re-run in a child process with it set."""
+    of both precisions are re-run in a child process with it set (not the uint8-frame test: that entry point has no LDS-DMA
+    form and compares against the register-staged kernel bit for bit)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FDET_STEM_DMA="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", os.path.join(root, "tests", "test_gpu_ps.py"),
-                        os.path.join(root, "tests", "test_gpu_p16.py"), "-k", "stem and not opt_in"], env=env, capture_output=True,
+                        os.path.join(root, "tests", "test_gpu_p16.py"), "-k", "stem and not opt_in and not uint8"], env=env, capture_output=True,
                        text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -190,6 +190,28 @@ def test_stem_fwd_ps(env, N):
     assert int((y.buf.view(torch.int16)[real.buf.view(torch.int16) == 0] != 0).sum()) == 0
 
 
+@pytest.mark.parametrize("N", [1, 3])
+@pytest.mark.parametrize("p16", [False, True])
+def test_stem_fwd_ps_on_uint8_frames(env, N, p16):
+    """fdet_stem_fwd_ps_u8: the stem reading the uint8 frames (x / 255 through its 256-entry hi | lo table) writes exactly the
+    bytes of fdet_u8_to_f32_norm + fdet_stem_fwd_ps -- every value 0..255 occurs, an all-zero and an all-255 frame row included."""
+    hp, ps = env
+    g = torch.Generator().manual_seed(10 + N)
+    fr = torch.randint(0, 256, (N, 3, 480, 480), dtype=torch.uint8, generator=g)
+    fr[0, :, 0] = 0
+    fr[0, :, 1] = 255
+    fr[0, 0, 2, :256] = torch.arange(256, dtype=torch.uint8)
+    w = torch.randn(64, 3, 10, 10, generator=g) * 0.05
+    b = torch.randn(64, generator=g)
+    fd = fr.cuda()
+    y_ref = ps.PsTensor(N, 64, 60, 60, "cuda")
+    ps.stem_fwd_ps(hp.u8_to_f32_norm(fd), w.cuda(), b.cuda(), y_ref, 10, 8, 2, p16=p16)
+    y = ps.PsTensor(N, 64, 60, 60, "cuda")
+    ps.stem_fwd_ps(fd, w.cuda(), b.cuda(), y, 10, 8, 2, p16=p16)
+    assert torch.equal(y.buf.view(torch.int32), y_ref.buf.view(torch.int32))
+    close(y.to_f32(), F.conv2d(fr.float() / 255.0, w, b, stride=8, padding=2), 1e-4 if not p16 else 2e-2)
+
+
 @pytest.mark.parametrize("cfg", [(3, 15, 15, 3, True), (2, 10, 10, 2, False), (5, 15, 15, 8, True), (1, 7, 9, 1, True)])
 def test_block_chain_ps_flavour(env, cfg):
     """The LDS-resident block chain keeping its per-block tensors in PS (fdet_block_chain_{fwd,bwd}_ps) against torch CPU
