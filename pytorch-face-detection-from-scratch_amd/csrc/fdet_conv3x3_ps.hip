@@ -708,6 +708,8 @@ int run_ps(int mode, const void* x, const void* wpk, const float* bias, const vo
   // maps wider than 62 columns run as column strips (fdet_ps.h): N, W below are those of the strip-images
   FDET_REQUIRE(ps_geo_strips(N, Cin, H, W, gi, sp) && ps_geo_strips(N, Cout, H, W, go, spo) && gi.WP >= 32 && sp.Ws + 2 <= gi.WP,
                "conv3x3_ps: unsupported map %dx%d (W + 2 <= 32 or 64 slots, or an even width in strips)", H, W);
+  FDET_REQUIRE((size_t)(gi.N + 2) * gi.img * 16 < ((size_t)1 << 32) && (size_t)(go.N + 2) * go.img * 16 < ((size_t)1 << 32),
+               "conv3x3_ps: tensor too large for the 32-bit byte offsets of the DMA descriptors (N=%d H=%d W=%d)", N, H, W);
   const int Nimg = N, Wfull = W;
   N = gi.N; W = sp.Ws;
   FDET_REQUIRE(slope >= 0.f && slope <= 1.f, "conv3x3_ps: slope must be in [0, 1]");

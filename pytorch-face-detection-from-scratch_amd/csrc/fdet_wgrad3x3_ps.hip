@@ -339,7 +339,7 @@ int wg_plan(int L, int N, int H, int W, PsGeo& g, int& nslab, int& lpw) {
   if (!ps_geo_strips(N, 64, H, W, g, sp) || L < 1 || L > WG_MAXL) return 0;
   const int lpi = g.HP * g.WP / 64;
   const long nlines = (long)g.N * lpi;
-  if (nlines + 2 * lpi >= (1 << 20)) return 0;
+  if (nlines + 2 * lpi >= (1 << 20) || (size_t)(g.N + 2) * g.img * 16 >= ((size_t)1 << 32)) return 0;   // 32-bit DMA byte offsets
   nslab = std::max(1, std::min((int)nlines, wg_num_cus() / L));
   lpw = (int)((nlines + nslab - 1) / nslab);
   nslab = (int)((nlines + lpw - 1) / lpw);

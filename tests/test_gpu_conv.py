@@ -404,7 +404,8 @@ def test_pooled_block_fused_into_conv_epilogues(hp, shape):
 
 
 PW_SHAPES = [(2, 16, 32, 24, 24), (3, 32, 64, 60, 60), (2, 64, 128, 15, 15), (2, 128, 256, 30, 30), (2, 256, 5, 15, 15),
-             (3, 256, 5, 7, 7), (1, 128, 5, 60, 60), (2, 24, 40, 9, 13), (1, 3, 7, 5, 6)]
+             (3, 256, 5, 7, 7), (1, 128, 5, 60, 60), (2, 24, 40, 9, 13), (1, 3, 7, 5, 6),
+             (1, 160, 288, 6, 6), (2, 288, 96, 5, 7)]      # (the last two: beyond the one-workgroup-per-slab weight gradient)
 
 
 @pytest.mark.parametrize("shape", PW_SHAPES)
