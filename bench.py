@@ -430,6 +430,28 @@ def extra_configs(device):
                 "mfma_floor_ms": round(t_mfma, 3), "hbm_floor_ms": round(t_hbm, 3) if mb else None,
                 "frac_of_max_floor": round(max(t_mfma, t_hbm) / ms, 4)}
 
+    # config 2: the headline model at batch 64 on one GPU (BASELINE.json configs[1] as written: "bs=64 one training step")
+    try:
+        from fdet_amd.models.PoolResnet import PoolResnet
+        from fdet_amd.convstack import KernelTimer
+        B, size, S = 64, 480, 10
+        torch.manual_seed(0)
+        model = PoolResnet(filters=64, input_shape=(3, size, size), num_of_patches=S, num_of_residual_blocks=10).to(device).train()
+        mm = ModelMeta(model=model, lr=1e-4); mm.configure_optimizers()
+        x = torch.rand(B, 3, size, size, generator=g).to(device)
+        y = hp.encode_targets(synthetic_boxes(B, size, seed=4), (size, size), S, device=device)
+        dt, r = _time_steps(lambda: mm.fused_train_step(x, y), 3, 10)
+        timer = KernelTimer(); model.engine.timer = timer
+        mm.fused_train_step(x, y)
+        model.engine.timer = None
+        out["config2_bs64_1gpu"] = {
+            "workload": "PoolResnet-medium 3x480x480, bs 64, fwd + YoloLoss + bwd + Adam (the headline kernels at a quarter of the batch)",
+            "ms_per_step": round(dt * 1e3, 3), "imgs_per_s": round(B / dt, 1), "finite_loss": bool(torch.isfinite(r[0]).all()),
+            **floors(B * STEP_GFLOP_PER_IMAGE_F64, B * STEP_MB_PER_IMAGE_F64 if "STEP_MB_PER_IMAGE_F64" in globals() else 0.0, 3.0, dt * 1e3),
+            "kernels_ms_per_step": {k: round(tot, 4) for k, (n_l, tot, fl, nb) in sorted(timer.summary().items(), key=lambda kv: -kv[1][1])[:8]}}
+        del model, mm, x, y
+    except Exception as e:                                   # noqa: BLE001
+        out["config2_bs64_1gpu"] = {"error": repr(e)[:300]}
     # config 3: Resnet-64 at 640^2, S=20, 32 images per GPU (global batch 256 on 8 GPUs)
     try:
         B, size, S = 32, 640, 20
