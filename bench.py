@@ -572,7 +572,11 @@ def extra_configs(device):
                 opt_t.zero_grad(); o["loss"].backward(); opt_t.step()
                 return o["loss"]
             dtt, lt = _time_steps(tstep, 1, 3)
-            train_ms = {"ms_per_step_bs32": round(dtt * 1e3, 2), "imgs_per_s": round(Bt / dtt, 1), "finite_loss": bool(torch.isfinite(lt))}
+            train_ms = {"ms_per_step_bs32": round(dtt * 1e3, 2), "imgs_per_s": round(Bt / dtt, 1), "finite_loss": bool(torch.isfinite(lt)),
+                        "what": "ModelMeta.training_step (metrics block on) + loss.backward() + SAMSGD.step(): the reference's Lightning-style path"}
+            # the same update without the autograd graph / per-parameter gradient copies / metrics (ModelMeta.fused_train_step)
+            dtf, lf = _time_steps(lambda: mmt.fused_train_step(xt, yt)[0], 2, 5)
+            train_ms["fused"] = {"ms_per_step_bs32": round(dtf * 1e3, 2), "imgs_per_s": round(Bt / dtf, 1), "finite_loss": bool(torch.isfinite(lf).all())}
             net.eval()
         except Exception as e:                               # noqa: BLE001
             train_ms = {"error": repr(e)[:200]}

@@ -129,92 +129,106 @@ k_mbt_taps_finish(const double* __restrict__ part, float* __restrict__ out, int 
 // ---------------------------------------------------------------------------------------------------------------------
 // depthwise conv k x k, stride 1 (pad k/2) or stride 2 (TF SAME), no bias: forward, data gradient, weight gradient
 // ---------------------------------------------------------------------------------------------------------------------
+// (round 4b: one plane (n, c) per blockIdx.x, 256 positions of it per blockIdx.y; k and the stride are template parameters, the
+//  row of a position comes from a multiply-high with ceil(2^32 / width) -- exact for positions < 2^20 and widths < 2^12 --
+//  so no kernel of this family divides per element any more)
+__device__ __forceinline__ int mbt_div(int v, unsigned magic) { return magic ? (int)__umulhi((unsigned)v, magic) : v; }
+
+template <int K, int S>
 __global__ void __launch_bounds__(256)
-k_mbt_dw_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z, int N, int C, int H, int W, int Ho,
-             int Wo, int k, int s, int pt, int pl) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = (long long)N * C * Ho * Wo;
-  if (t >= total) return;
-  const int ox = (int)(t % Wo), oy = (int)((t / Wo) % Ho);
-  const long long nc = t / ((long long)Wo * Ho);
-  const int c = (int)(nc % C);
+k_mbt_dw_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z, int C, int H, int W, int Ho, int Wo,
+             int pt, int pl, unsigned magic_wo) {
+  const int nc = blockIdx.x, r = blockIdx.y * 256 + threadIdx.x;
+  if (r >= Ho * Wo) return;
+  const int oy = mbt_div(r, magic_wo), ox = r - oy * Wo;
+  const int c = nc % C;
   const float* xp = x + (size_t)nc * H * W;
-  const float* wp = w + (size_t)c * k * k;
+  const float* wp = w + (size_t)c * K * K;
   float acc = 0.f;
-  for (int ky = 0; ky < k; ++ky) {
-    const int iy = oy * s - pt + ky;
-    if (iy < 0 || iy >= H) continue;
-    for (int kx = 0; kx < k; ++kx) {
-      const int ix = ox * s - pl + kx;
-      if (ix < 0 || ix >= W) continue;
-      acc = fmaf(xp[(size_t)iy * W + ix], wp[ky * k + kx], acc);
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int iy = oy * S - pt + ky;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int ix = ox * S - pl + kx;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      acc = fmaf(ok ? xp[(size_t)iy * W + ix] : 0.f, wp[ky * K + kx], acc);
     }
   }
-  z[t] = acc;
+  z[(size_t)nc * Ho * Wo + r] = acc;
 }
 
 // dx[n][c][iy][ix] = sum_{ky,kx : (iy + pt - ky) % s == 0 ...} dz[n][c][(iy + pt - ky)/s][(ix + pl - kx)/s] * w[c][ky][kx]
+template <int K, int S>
 __global__ void __launch_bounds__(256)
-k_mbt_dw_bwd_data(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx, int N, int C, int H, int W,
-                  int Ho, int Wo, int k, int s, int pt, int pl) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = (long long)N * C * H * W;
-  if (t >= total) return;
-  const int ix = (int)(t % W), iy = (int)((t / W) % H);
-  const long long nc = t / ((long long)W * H);
-  const int c = (int)(nc % C);
+k_mbt_dw_bwd_data(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx, int C, int H, int W, int Ho,
+                  int Wo, int pt, int pl, unsigned magic_w) {
+  const int nc = blockIdx.x, r = blockIdx.y * 256 + threadIdx.x;
+  if (r >= H * W) return;
+  const int iy = mbt_div(r, magic_w), ix = r - iy * W;
+  const int c = nc % C;
   const float* zp = dz + (size_t)nc * Ho * Wo;
-  const float* wp = w + (size_t)c * k * k;
+  const float* wp = w + (size_t)c * K * K;
   float acc = 0.f;
-  for (int ky = 0; ky < k; ++ky) {
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
     const int a = iy + pt - ky;
-    if (a < 0 || a % s) continue;
-    const int oy = a / s;
-    if (oy >= Ho) continue;
-    for (int kx = 0; kx < k; ++kx) {
+    const int oy = S == 1 ? a : a >> 1;
+    const bool oky = a >= 0 && (S == 1 || !(a & 1)) && oy < Ho;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
       const int b = ix + pl - kx;
-      if (b < 0 || b % s) continue;
-      const int ox = b / s;
-      if (ox >= Wo) continue;
-      acc = fmaf(zp[(size_t)oy * Wo + ox], wp[ky * k + kx], acc);
+      const int ox = S == 1 ? b : b >> 1;
+      const bool ok = oky && b >= 0 && (S == 1 || !(b & 1)) && ox < Wo;
+      acc = fmaf(ok ? zp[(size_t)oy * Wo + ox] : 0.f, wp[ky * K + kx], acc);
     }
   }
-  dx[t] = acc;
+  dx[(size_t)nc * H * W + r] = acc;
 }
 
-// dW[c][ky][kx] = sum_{n,oy,ox} dz * x: one block per (channel, slice); a thread keeps the k*k taps of its positions
-template <int K>
+// dW[c][ky][kx] = sum_{n,oy,ox} dz * x.  The (image, 2048-position chunk) pairs of a channel are dealt to the TAP_SPLIT slices in
+// turn; a thread keeps the k*k taps of its positions in registers; one LDS pass combines the waves.
+template <int K, int S>
 __global__ void __launch_bounds__(256)
 k_mbt_dw_bwd_weight(const float* __restrict__ x, const float* __restrict__ dz, double* __restrict__ part, int N, int C, int H, int W,
-                    int Ho, int Wo, int s, int pt, int pl) {
-  __shared__ double sh[16];
-  constexpr int kk = K * K;
+                    int Ho, int Wo, int pt, int pl, unsigned magic_wo) {
+  constexpr int kk = K * K, CH = 2048;
+  __shared__ float sh[4][kk];
   const int c = blockIdx.x, j = blockIdx.y;
-  const long long per = (long long)Ho * Wo, total = (long long)N * per;
-  const long long lo = total * j / TAP_SPLIT, hi = total * (j + 1) / TAP_SPLIT;
+  const int per = Ho * Wo, cpp = (per + CH - 1) / CH, nchunk = N * cpp;
   float acc[kk];
 #pragma unroll
   for (int t = 0; t < kk; ++t) acc[t] = 0.f;
-  for (long long t = lo + threadIdx.x; t < hi; t += 256) {
-    const int n = (int)(t / per);
-    const int r = (int)(t % per), oy = r / Wo, ox = r % Wo;
-    const float g = dz[((size_t)n * C + c) * per + r];
+  for (int q = j; q < nchunk; q += TAP_SPLIT) {
+    const int n = q / cpp, r0 = (q - n * cpp) * CH, r1 = min(per, r0 + CH);
+    const float* zp = dz + ((size_t)n * C + c) * per;
     const float* xp = x + ((size_t)n * C + c) * H * W;
+    for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+      const int oy = mbt_div(r, magic_wo), ox = r - oy * Wo;
+      const float g = zp[r];
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-      const int iy = oy * s - pt + ky;
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * S - pt + ky;
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const int ix = ox * s - pl + kx;
-        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-        acc[ky * K + kx] = fmaf(g, ok ? xp[(size_t)iy * W + ix] : 0.f, acc[ky * K + kx]);
+        for (int kx = 0; kx < K; ++kx) {
+          const int ix = ox * S - pl + kx;
+          const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+          acc[ky * K + kx] = fmaf(g, ok ? xp[(size_t)iy * W + ix] : 0.f, acc[ky * K + kx]);
+        }
       }
     }
   }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int t = 0; t < kk; ++t) {
-    const double tot = block_sum((double)acc[t], sh);
-    if (threadIdx.x == 0) part[((size_t)c * TAP_SPLIT + j) * kk + t] = tot;
+    float v = acc[t];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) sh[wv][t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kk) {
+    const int t = threadIdx.x;
+    part[((size_t)c * TAP_SPLIT + j) * kk + t] = ((double)sh[0][t] + (double)sh[1][t]) + ((double)sh[2][t] + (double)sh[3][t]);
   }
 }
 
@@ -223,18 +237,21 @@ k_mbt_dw_bwd_weight(const float* __restrict__ x, const float* __restrict__ dz, d
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int BN_SPLIT = 32;
 
-// partial sums of one channel over a slice of the (n, p) space: ws[(c * BN_SPLIT + j) * 2 + {0,1}] = sum, sum of squares
-__global__ void __launch_bounds__(1024)
+// partial sums of one channel: the (image, 2048-position chunk) pairs are dealt to the BN_SPLIT slices in turn (no per-element
+// division); ws[(c * BN_SPLIT + j) * 2 + {0,1}] = sum, sum of squares
+constexpr int BN_CH = 2048;
+__global__ void __launch_bounds__(256)
 k_mbt_bn_partial(const float* __restrict__ z, double* __restrict__ ws, int N, int C, int P) {
   __shared__ double sh[16];
   const int c = blockIdx.x, j = blockIdx.y;
-  const long long total = (long long)N * P;
-  const long long lo = total * j / BN_SPLIT, hi = total * (j + 1) / BN_SPLIT;
+  const int cpp = (P + BN_CH - 1) / BN_CH, nchunk = N * cpp;
   double s = 0.0, q = 0.0;
-  for (long long t = lo + threadIdx.x; t < hi; t += 1024) {
-    const int n = (int)(t / P), p = (int)(t % P);
-    const double v = (double)z[((size_t)n * C + c) * P + p];
-    s += v; q += v * v;
+  for (int k = j; k < nchunk; k += BN_SPLIT) {
+    const int n = k / cpp, p0 = (k - n * cpp) * BN_CH, p1 = min(P, p0 + BN_CH);
+    const float* zp = z + ((size_t)n * C + c) * P;
+    float s4 = 0.f, q4 = 0.f;                              // <= 8 elements per thread and chunk in fp32, chunks added in fp64
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) { const float v = zp[p]; s4 += v; q4 = fmaf(v, v, q4); }
+    s += (double)s4; q += (double)q4;
   }
   const double ts = block_sum(s, sh);
   const double tq = block_sum(q, sh);
@@ -262,37 +279,41 @@ k_mbt_bn_finish(const double* __restrict__ ws, float* __restrict__ mean, float* 
   }
 }
 
-// y = act(gamma * (z - mean) * invstd + beta) (+ residual)
+// y = act(gamma * (z - mean) * invstd + beta) (+ residual); blockIdx.x = plane (n, c), blockIdx.y = 256-position piece
 __global__ void __launch_bounds__(256)
 k_mbt_bn_apply(const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
                const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ residual,
-               float* __restrict__ y, int C, int P, long long total, int act) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  const int c = (int)((t / P) % C);
+               float* __restrict__ y, int C, int P, int act) {
+  const int p = blockIdx.y * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int c = blockIdx.x % C;
+  const size_t t = (size_t)blockIdx.x * P + p;
   const float u = gamma[c] * ((z[t] - mean[c]) * invstd[c]) + beta[c];
   float v = mbt_act(u, act);
   if (residual) v += residual[t];
   y[t] = v;
 }
 
-// backward, pass 1: g = dy * act'(u); per channel S1 = sum g, S2 = sum g * xhat (partials per slice)
-__global__ void __launch_bounds__(1024)
+// backward, pass 1: g = dy * act'(u); per channel S1 = sum g, S2 = sum g * xhat (partials per slice, chunks as k_mbt_bn_partial)
+__global__ void __launch_bounds__(256)
 k_mbt_bn_bwd_partial(const float* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ gamma,
                      const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
                      double* __restrict__ ws, int N, int C, int P, int act) {
   __shared__ double sh[16];
   const int c = blockIdx.x, j = blockIdx.y;
-  const long long total = (long long)N * P;
-  const long long lo = total * j / BN_SPLIT, hi = total * (j + 1) / BN_SPLIT;
+  const int cpp = (P + BN_CH - 1) / BN_CH, nchunk = N * cpp;
   const float ga = gamma[c], be = beta[c], mu = mean[c], is = invstd[c];
   double s1 = 0.0, s2 = 0.0;
-  for (long long t = lo + threadIdx.x; t < hi; t += 1024) {
-    const int n = (int)(t / P), p = (int)(t % P);
-    const size_t e = ((size_t)n * C + c) * P + p;
-    const float xh = (z[e] - mu) * is;
-    const float g = dy[e] * mbt_dact(ga * xh + be, act);
-    s1 += (double)g; s2 += (double)g * (double)xh;
+  for (int k = j; k < nchunk; k += BN_SPLIT) {
+    const int n = k / cpp, p0 = (k - n * cpp) * BN_CH, p1 = min(P, p0 + BN_CH);
+    const size_t base = ((size_t)n * C + c) * P;
+    float a1 = 0.f, a2 = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+      const float xh = (z[base + p] - mu) * is;
+      const float g = dy[base + p] * mbt_dact(ga * xh + be, act);
+      a1 += g; a2 = fmaf(g, xh, a2);
+    }
+    s1 += (double)a1; s2 += (double)a2;
   }
   const double t1 = block_sum(s1, sh);
   const double t2 = block_sum(s2, sh);
@@ -311,14 +332,15 @@ k_mbt_bn_bwd_finish(const double* __restrict__ ws, float* __restrict__ dgamma, f
   s12[2 * c] = (float)s1; s12[2 * c + 1] = (float)s2;
 }
 
-// pass 2: dz = gamma * invstd * (g - S1 / M - xhat * S2 / M)
+// pass 2: dz = gamma * invstd * (g - S1 / M - xhat * S2 / M); blockIdx.x = plane (n, c)
 __global__ void __launch_bounds__(256)
 k_mbt_bn_bwd_apply(const float* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ gamma,
                    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
-                   const float* __restrict__ s12, float* __restrict__ dz, int C, int P, long long total, float inv_m, int act) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  const int c = (int)((t / P) % C);
+                   const float* __restrict__ s12, float* __restrict__ dz, int C, int P, float inv_m, int act) {
+  const int p = blockIdx.y * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int c = blockIdx.x % C;
+  const size_t t = (size_t)blockIdx.x * P + p;
   const float xh = (z[t] - mean[c]) * invstd[c];
   const float g = dy[t] * mbt_dact(gamma[c] * xh + beta[c], act);
   dz[t] = gamma[c] * invstd[c] * (g - s12[2 * c] * inv_m - xh * (s12[2 * c + 1] * inv_m));
@@ -365,10 +387,11 @@ k_mbt_se_fc(const float* __restrict__ pooled, const float* __restrict__ w1, cons
 }
 
 __global__ void __launch_bounds__(256)
-k_mbt_se_scale(const float* __restrict__ x, const float* __restrict__ pre, float* __restrict__ y, int P, long long total) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  y[t] = x[t] * hsig(pre[t / P]);
+k_mbt_se_scale(const float* __restrict__ x, const float* __restrict__ pre, float* __restrict__ y, int P) {
+  const int p = blockIdx.y * 256 + threadIdx.x;            // blockIdx.x = plane (n, c)
+  if (p >= P) return;
+  const size_t t = (size_t)blockIdx.x * P + p;
+  y[t] = x[t] * hsig(pre[blockIdx.x]);
 }
 
 // backward 1: dpre[n][c] = hardsigmoid'(pre) * sum_p dy * x  (one wave per plane)
@@ -409,14 +432,14 @@ k_mbt_se_bwd_fc(const float* __restrict__ dpre, const float* __restrict__ hidden
   }
 }
 
-// backward 3: dx = dy * hardsigmoid(pre) + dpool
+// backward 3: dx = dy * hardsigmoid(pre) + dpool; blockIdx.x = plane (n, c)
 __global__ void __launch_bounds__(256)
 k_mbt_se_bwd_apply(const float* __restrict__ dy, const float* __restrict__ pre, const float* __restrict__ dpool, float* __restrict__ dx,
-                   int P, long long total) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  const long long pl = t / P;
-  dx[t] = dy[t] * hsig(pre[pl]) + dpool[pl];
+                   int P) {
+  const int p = blockIdx.y * 256 + threadIdx.x;
+  if (p >= P) return;
+  const size_t t = (size_t)blockIdx.x * P + p;
+  dx[t] = dy[t] * hsig(pre[blockIdx.x]) + dpool[blockIdx.x];
 }
 
 // dW2[c][r] = sum_n dpre[n][c] * relu(hidden[n][r]); db2[c] = sum_n dpre; dW1[r][c] = sum_n dhid[n][r] * pooled[n][c]; db1[r] = sum_n dhid
@@ -450,6 +473,7 @@ k_mbt_se_wreduce(const float* __restrict__ dpre, const float* __restrict__ dhid,
 }
 
 inline unsigned nblk(long long total, int per) { return (unsigned)((total + per - 1) / per); }
+inline unsigned mbt_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }   // see mbt_div
 
 }  // namespace
 
@@ -491,8 +515,13 @@ bool dw_geo(int H, int W, int k, int s, int& Ho, int& Wo, int& pt, int& pl) {
 extern "C" int fdet_mbt_dw_fwd(const float* x, const float* w, float* z, int N, int C, int H, int W, int k, int s, void* stream) {
   int Ho, Wo, pt, pl;
   FDET_REQUIRE(x && w && z && N > 0 && C > 0 && dw_geo(H, W, k, s, Ho, Wo, pt, pl), "mbt_dw_fwd: bad arguments (k 3|5, stride 1|2)");
-  const long long total = (long long)N * C * Ho * Wo;
-  hipLaunchKernelGGL(k_mbt_dw_fwd, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w, z, N, C, H, W, Ho, Wo, k, s, pt, pl);
+  FDET_REQUIRE((long long)H * W < (1 << 20) && W < 4096, "mbt_dw_fwd: plane too large");
+  const dim3 grid((unsigned)(N * C), (unsigned)((Ho * Wo + 255) / 256));
+  const unsigned mg = mbt_magic(Wo);
+  hipStream_t st = (hipStream_t)stream;
+#define MBT_DW_FWD(K_, S_) hipLaunchKernelGGL((k_mbt_dw_fwd<K_, S_>), grid, dim3(256), 0, st, x, w, z, C, H, W, Ho, Wo, pt, pl, mg)
+  if (k == 3 && s == 1) MBT_DW_FWD(3, 1); else if (k == 3) MBT_DW_FWD(3, 2); else if (s == 1) MBT_DW_FWD(5, 1); else MBT_DW_FWD(5, 2);
+#undef MBT_DW_FWD
   return check_launch("fdet_mbt_dw_fwd");
 }
 
@@ -502,12 +531,18 @@ extern "C" int fdet_mbt_dw_bwd(const float* x, const float* dz, const float* w, 
   int Ho, Wo, pt, pl;
   FDET_REQUIRE(x && dz && w && dx && dW && ws && N > 0 && C > 0 && dw_geo(H, W, k, s, Ho, Wo, pt, pl), "mbt_dw_bwd: bad arguments");
   FDET_REQUIRE(ws_bytes >= fdet_mbt_taps_ws_bytes(C, k), "mbt_dw_bwd: workspace too small");
-  const long long total = (long long)N * C * H * W;
+  FDET_REQUIRE((long long)H * W < (1 << 20) && W < 4096, "mbt_dw_bwd: plane too large");
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(k_mbt_dw_bwd_data, dim3(nblk(total, 256)), dim3(256), 0, st, dz, w, dx, N, C, H, W, Ho, Wo, k, s, pt, pl);
-  if (k == 3) hipLaunchKernelGGL(k_mbt_dw_bwd_weight<3>, dim3(C, TAP_SPLIT), dim3(256), 0, st, x, dz, part, N, C, H, W, Ho, Wo, s, pt, pl);
-  else hipLaunchKernelGGL(k_mbt_dw_bwd_weight<5>, dim3(C, TAP_SPLIT), dim3(256), 0, st, x, dz, part, N, C, H, W, Ho, Wo, s, pt, pl);
+  const dim3 gd((unsigned)(N * C), (unsigned)((H * W + 255) / 256)), gw((unsigned)C, TAP_SPLIT);
+  const unsigned mw = mbt_magic(W), mo = mbt_magic(Wo);
+#define MBT_DW_BWD(K_, S_)                                                                                                          \
+  {                                                                                                                                  \
+    hipLaunchKernelGGL((k_mbt_dw_bwd_data<K_, S_>), gd, dim3(256), 0, st, dz, w, dx, C, H, W, Ho, Wo, pt, pl, mw);                    \
+    hipLaunchKernelGGL((k_mbt_dw_bwd_weight<K_, S_>), gw, dim3(256), 0, st, x, dz, part, N, C, H, W, Ho, Wo, pt, pl, mo);             \
+  }
+  if (k == 3 && s == 1) MBT_DW_BWD(3, 1) else if (k == 3) MBT_DW_BWD(3, 2) else if (s == 1) MBT_DW_BWD(5, 1) else MBT_DW_BWD(5, 2)
+#undef MBT_DW_BWD
   hipLaunchKernelGGL(k_mbt_taps_finish, dim3((C * k * k + 255) / 256), dim3(256), 0, st, part, dW, C, k * k);
   return check_launch("fdet_mbt_dw_bwd");
 }
@@ -524,12 +559,11 @@ extern "C" int fdet_mbt_bn_fwd(const float* z, const float* gamma, const float* 
   FDET_REQUIRE(ws_bytes >= fdet_mbt_bn_ws_bytes(C), "mbt_bn_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   double* wsd = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(k_mbt_bn_partial, dim3(C, BN_SPLIT), dim3(1024), 0, st, z, wsd, N, C, P);
+  hipLaunchKernelGGL(k_mbt_bn_partial, dim3(C, BN_SPLIT), dim3(256), 0, st, z, wsd, N, C, P);
   hipLaunchKernelGGL(k_mbt_bn_finish, dim3((C + 63) / 64), dim3(64), 0, st, wsd, save_mean, save_invstd, running_mean, running_var, C,
                      (long long)N * P, momentum, eps);
-  const long long total = (long long)N * C * P;
-  hipLaunchKernelGGL(k_mbt_bn_apply, dim3(nblk(total, 256)), dim3(256), 0, st, z, gamma, beta, save_mean, save_invstd, residual, y, C, P,
-                     total, act);
+  hipLaunchKernelGGL(k_mbt_bn_apply, dim3((unsigned)(N * C), (unsigned)((P + 255) / 256)), dim3(256), 0, st, z, gamma, beta, save_mean,
+                     save_invstd, residual, y, C, P, act);
   return check_launch("fdet_mbt_bn_fwd");
 }
 
@@ -543,11 +577,10 @@ extern "C" int fdet_mbt_bn_bwd(const float* z, const float* dy, const float* gam
   hipStream_t st = (hipStream_t)stream;
   double* wsd = reinterpret_cast<double*>(ws);
   float* s12 = reinterpret_cast<float*>(wsd + (size_t)C * BN_SPLIT * 2);
-  hipLaunchKernelGGL(k_mbt_bn_bwd_partial, dim3(C, BN_SPLIT), dim3(1024), 0, st, z, dy, gamma, beta, save_mean, save_invstd, wsd, N, C, P, act);
+  hipLaunchKernelGGL(k_mbt_bn_bwd_partial, dim3(C, BN_SPLIT), dim3(256), 0, st, z, dy, gamma, beta, save_mean, save_invstd, wsd, N, C, P, act);
   hipLaunchKernelGGL(k_mbt_bn_bwd_finish, dim3((C + 63) / 64), dim3(64), 0, st, wsd, dgamma, dbeta, s12, C);
-  const long long total = (long long)N * C * P;
-  hipLaunchKernelGGL(k_mbt_bn_bwd_apply, dim3(nblk(total, 256)), dim3(256), 0, st, z, dy, gamma, beta, save_mean, save_invstd, s12, dz, C, P,
-                     total, 1.f / (float)((long long)N * P), act);
+  hipLaunchKernelGGL(k_mbt_bn_bwd_apply, dim3((unsigned)(N * C), (unsigned)((P + 255) / 256)), dim3(256), 0, st, z, dy, gamma, beta,
+                     save_mean, save_invstd, s12, dz, C, P, 1.f / (float)((long long)N * P), act);
   return check_launch("fdet_mbt_bn_bwd");
 }
 
@@ -558,8 +591,7 @@ extern "C" int fdet_mbt_se_fwd(const float* x, const float* w1, const float* b1,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_mbt_se_pool, dim3((N * C + 3) / 4), dim3(256), 0, st, x, pooled, N * C, P);
   hipLaunchKernelGGL(k_mbt_se_fc, dim3(N), dim3(256), (size_t)(C + R) * 4, st, pooled, w1, b1, w2, b2, hidden, pre, C, R);
-  const long long total = (long long)N * C * P;
-  hipLaunchKernelGGL(k_mbt_se_scale, dim3(nblk(total, 256)), dim3(256), 0, st, x, pre, y, P, total);
+  hipLaunchKernelGGL(k_mbt_se_scale, dim3((unsigned)(N * C), (unsigned)((P + 255) / 256)), dim3(256), 0, st, x, pre, y, P);
   return check_launch("fdet_mbt_se_fwd");
 }
 
@@ -575,8 +607,7 @@ extern "C" int fdet_mbt_se_bwd(const float* x, const float* dy, const float* poo
   float* dpool = dhid + (size_t)N * R;
   hipLaunchKernelGGL(k_mbt_se_bwd_gate, dim3((N * C + 3) / 4), dim3(256), 0, st, x, dy, pre, dpre, N * C, P);
   hipLaunchKernelGGL(k_mbt_se_bwd_fc, dim3(N), dim3(256), (size_t)(C + R) * 4, st, dpre, hidden, w1, w2, dhid, dpool, C, R, P);
-  { const long long total = (long long)N * C * P;
-    hipLaunchKernelGGL(k_mbt_se_bwd_apply, dim3(nblk(total, 256)), dim3(256), 0, st, dy, pre, dpool, dx, P, total); }
+  hipLaunchKernelGGL(k_mbt_se_bwd_apply, dim3((unsigned)(N * C), (unsigned)((P + 255) / 256)), dim3(256), 0, st, dy, pre, dpool, dx, P);
   const int tot = 2 * C * R + C + R;
   hipLaunchKernelGGL(k_mbt_se_wreduce, dim3((tot + 255) / 256), dim3(256), 0, st, dpre, dhid, pooled, hidden, dw1, db1, dw2, db2, N, C, R);
   return check_launch("fdet_mbt_se_bwd");

@@ -88,6 +88,8 @@ class ModelMeta(_Base):
         Returns (loss_sum (1,), y_hat, metrics or None) -- GPU tensors, no host sync."""
         if self.opt is None:
             self.configure_optimizers()
+        if hasattr(self.model, "_train_engine"):
+            return self._fused_train_step_mobilenet(x, y, with_metrics)
         model, eng = self.model, self.model.engine
         names, params = model.named_stack_params()
         opt = self.opt
@@ -118,6 +120,42 @@ class ModelMeta(_Base):
         eng.backward(saved, dy, P, G,
                      after_block=(lambda k: red.launch_tail() if k == self._split_block else None) if red.enabled else None)
         if red.enabled:
+            red.launch_head()
+            red.wait()
+        opt.step(grads_in_flat=True)
+        metrics = self._metrics(y_hat, y) if with_metrics else None
+        return lsum, y_hat, metrics
+
+    def _fused_train_step_mobilenet(self, x, y, with_metrics: bool = False):
+        """The same step for `MobilenetV3Backbone` (mobilenet_train.py): training-mode forward (BatchNorm batch statistics,
+        running statistics updated), yolo_loss, the hand-written backward writing straight into the optimiser's flat gradient
+        buffer, SUM all-reduce under torch.distributed, Adam -- no autograd graph, no per-parameter gradient copies (the
+        Lightning-style training_step + loss.backward() + optimizer.step() path stays available and gives the same update)."""
+        model, opt = self.model, self.opt
+        if not x.is_cuda:
+            raise hp.N.FdetError("the MobileNet training path runs on the GPU only (no CPU fallback): move model and input to cuda")
+        params = dict(model.named_parameters())
+        names = list(params.keys())
+        sp = opt._space()
+        if [id(p) for p in sp.params] != [id(params[n]) for n in names]:
+            raise RuntimeError("optimizer parameter order differs from the model's")
+        P = {n: p.data for n, p in params.items()}
+        P.update({n: b for n, b in model.named_buffers()})
+        G = {n: sp.view(sp.grad, i) for i, n in enumerate(names)}
+        if self._reducer is None or self._reducer.flat.data_ptr() != sp.grad.data_ptr():
+            self._reducer = GradBucketReducer(sp.grad, sp.offsets[len(names) // 2])
+            if self._reducer.enabled:
+                sync_parameters(sp.flat)
+                P.update({n: p.data for n, p in params.items()})
+        red = self._reducer
+        was_training = model.training
+        if not was_training:
+            raise RuntimeError("fused_train_step: put the model in train() mode (BatchNorm batch statistics)")
+        y_hat, saved = model._train_engine.forward_train(x, P)
+        _, lsum, dy = hp.yolo_loss_fwd_bwd(y_hat, y, want_grad=True)
+        model._train_engine.backward(saved, dy, P, G)
+        if red.enabled:
+            red.launch_tail()
             red.launch_head()
             red.wait()
         opt.step(grads_in_flat=True)

@@ -228,3 +228,37 @@ def test_modelmeta_training_steps_on_mobilenet(L):
     with torch.no_grad():
         y = net(x)
     assert tuple(y.shape) == (B, 5, S, S) and bool(torch.isfinite(y).all())
+
+
+def test_fused_train_step_equals_the_autograd_path(L):
+    """ModelMeta.fused_train_step on the MobileNet backbone (forward_train -> yolo_loss -> backward into the optimiser's flat
+    gradient buffer -> Adam, no autograd graph) makes exactly the update of training_step + loss.backward() + SAMSGD.step():
+    same kernels, same order -- loss, parameters and BatchNorm running statistics bit-identical after three steps."""
+    import oracle as O
+    from oracle import mobilenet_oracle as MO
+    from fdet_amd.models import ModelMeta
+    size, S, B = 96, 3, 4
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(3)).cuda()
+    boxes = _boxes(B, size, seed=4)
+    yt = torch.stack([O.encode_targets(b, (size, size), S) for b in boxes]).cuda()
+    res = {}
+    for mode in ("autograd", "fused"):
+        net = _model(MO.init_params(seed=5), size, S).train()
+        mm = ModelMeta(model=net, lr=1e-3)
+        (opt,), _ = mm.configure_optimizers()
+        losses = []
+        for it in range(3):
+            if mode == "autograd":
+                out = mm.training_step((x, yt, boxes), it)
+                opt.zero_grad()
+                out["loss"].backward()
+                opt.step()
+                losses.append(float(out["loss"]))
+            else:
+                lsum, y_hat, _ = mm.fused_train_step(x, yt)
+                losses.append(float(lsum))
+        res[mode] = (losses, {k: v.detach().clone() for k, v in net.state_dict().items()})
+    (la, sa), (lf, sf) = res["autograd"], res["fused"]
+    assert la == lf, (la, lf)
+    for k in sa:
+        assert torch.equal(sa[k], sf[k]), k

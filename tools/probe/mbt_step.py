@@ -30,3 +30,11 @@ for _ in range(10):
     opt.zero_grad(); o["loss"].backward(); opt.step()
 torch.cuda.synchronize()
 print("ms/step", (time.perf_counter() - t0) * 100)
+for _ in range(3):
+    mm.fused_train_step(x, y)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    mm.fused_train_step(x, y)
+torch.cuda.synchronize()
+print("fused ms/step", (time.perf_counter() - t0) * 100)
