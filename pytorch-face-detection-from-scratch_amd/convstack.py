@@ -631,11 +631,13 @@ class ConvStack:
                     c = c.view(N, F_ // 8, 8, hk // 2, hk // 2).permute(0, 1, 3, 4, 2).contiguous()
                 fl = self._conv_flops(N, hk)
 
-                def wgrad_now(x_, dz_, nm_):
+                def wgrad_now(x_, dz_, nm_, clean=False):
                     # strips: the weight gradient wants ZERO halo slots in dz (a halo is not a position of its strip), the
                     # data-gradient conv behind it the neighbour columns -- so each layer's weight gradient runs right
-                    # here, between the two halo passes, instead of in the level's batched launch
-                    psm.halo_exchange(dz_, zero_only=True, p16=self.p16)
+                    # here, between the two halo passes, instead of in the level's batched launch (clean: the producer
+                    # cleared the halo slots itself)
+                    if not clean:
+                        psm.halo_exchange(dz_, zero_only=True, p16=self.p16)
                     pending_ps.append((x_, dz_, nm_))
                     flush_ps(hk)
                     psm.halo_exchange(dz_, p16=self.p16)
@@ -643,7 +645,7 @@ class ConvStack:
                 with self._t("pool_route_bwd", N, hk, 0.0, self._act_bytes(N, hk, 1 + 0.25 + 1 / 16)):
                     psm.pool_route_bwd_ps(dout, c, sc, dz2, self.slope, p16=self.p16)
                 if strips:
-                    wgrad_now(a, dz2, name + ".conv2")
+                    wgrad_now(a, dz2, name + ".conv2", clean=True)      # fdet_pool_route_bwd_ps clears dz2's halo slots
                 dz1 = self._ps_take(scope, N, F_, hk, hk, dev)
                 with self._t("conv3x3_dgrad", N, hk, fl, self._act_bytes(N, hk, 3)):
                     psm.conv3x3_ps_dgrad_act(dz2, self._wpk[name + ".conv2.b"], a, dz1, self.slope, p16=self.p16)

@@ -120,6 +120,20 @@ k_pool_route_bwd_ps(const float* __restrict__ dout, const unsigned char* __restr
     dz[u] = hi;
     if (!P16) dz[u + g.plane] = lo;                        // precision16: the hi plane only
   }
+  // strips: this tensor is the dz operand of the weight gradient next, whose halo slots must be zero (fdet_ps.h) -- the edge
+  // windows clear them here, which saves the separate fdet_ps_halo_exchange(zero_only) pass over a recycled buffer
+  if (st.S > 1) {
+    const ps_bf16x8 zero = {};
+    const bool left = xp == 0 && sidx > 0, right = xp == wsp - 1 && sidx + 1 < st.S;
+    if (left || right) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const size_t row = (size_t)ns * g.img + (size_t)(gr * g.HP + 2 * yp + rr) * g.WP;
+        if (left) { dz[row] = zero; if (!P16) dz[row + g.plane] = zero; }
+        if (right) { dz[row + st.Ws + 1] = zero; if (!P16) dz[row + st.Ws + 1 + g.plane] = zero; }
+      }
+    }
+  }
 }
 
 }  // namespace

@@ -144,8 +144,11 @@ def test_strip_pooled_block(env, shape, train):
         return
     # backward through the routing bytes: dz2 = unpool(dout) * scale * lrelu'(c); dx = conv^T(dz1) + unpool(dout)
     dout = torch.randn(N, C, H // 2, W // 2, generator=g)
-    dz2 = ps.PsTensor(N, C, H, W, "cuda")
+    dz2 = ps.PsTensor.from_f32(torch.randn(N, C, H, W, generator=g).cuda())      # a recycled buffer: data AND halo slots dirty
     ps.pool_route_bwd_ps(dout.cuda(), route, scale.cuda(), dz2, slope=0.2)
+    after = dz2.buf.view(torch.int32).clone()                  # the kernel cleared the halo slots itself (the weight gradient reads
+    ps.halo_exchange(dz2, zero_only=True)                      # dz2 next): the zero pass changes nothing
+    assert torch.equal(dz2.buf.view(torch.int32), after)
     un = F.max_unpool2d(dout, idx, 2, output_size=(H, W))
     ref_dz2 = un * scale[:, :, None, None] * torch.where(c > 0, 1.0, 0.2)
     got = dz2.to_f32().cpu()
