@@ -196,9 +196,11 @@ __device__ __forceinline__ void pw_load8(const float* __restrict__ row, int p, i
 }
 
 // one wave = one 32x32 block of dW over a slab of positions; workgroup = 4 waves = 4 consecutive (co-tile, ci-tile) blocks
+// (round 4: the bias gradient rides along -- the waves of input-channel tile 0 sum their dz fragments before splitting them,
+//  one partial per (slab, output channel); the separate pass over dz, k_pw_bias_part, is gone)
 template <bool VEC>
 __global__ void __launch_bounds__(256)
-k_pw_wgrad_x3(const PwWgArgs a) {
+k_pw_wgrad_x3(const PwWgArgs a, float* __restrict__ bias_part /*[nslab][CoT*32] or null*/) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int blk = blockIdx.x * 4 + wid;                 // (co tile, ci tile)
@@ -209,12 +211,18 @@ k_pw_wgrad_x3(const PwWgArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  const bool want_b = bias_part != nullptr && cit == 0;    // wave-uniform
   const int s0 = slab * a.steps_per_slab, s1 = min(s0 + a.steps_per_slab, a.steps_total);
   for (int s = s0; s < s1; ++s) {
     const int n = s / a.steps_per_img, p = (s - n * a.steps_per_img) * 16 + 8 * half;
     float fa[8], fb[8];
     pw_load8<VEC>(co < a.Cout ? a.dz + ((size_t)n * a.Cout + co) * a.P : nullptr, p, a.P, fa);
     pw_load8<VEC>(ci < a.Cin ? a.x + ((size_t)n * a.Cin + ci) * a.P : nullptr, p, a.P, fb);
+    if (want_b) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum += fa[j];
+    }
     bf16x8 ah, al, bh, bl;
     split8(fa, ah, al);
     split8(fb, bh, bl);
@@ -227,6 +235,27 @@ k_pw_wgrad_x3(const PwWgArgs a) {
   float* __restrict__ w = a.ws + ((size_t)slab * a.CoT * 32 + cot * 32) * ldw + cit * 32 + l31;
 #pragma unroll
   for (int r = 0; r < 16; ++r) w[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * ldw] = acc[r];
+  if (want_b) {
+    bsum += __shfl_xor(bsum, 32, 64);                      // the two k halves of a channel
+    if (half == 0) bias_part[(size_t)slab * a.CoT * 32 + cot * 32 + l31] = bsum;
+  }
+}
+
+// db[c] = sum over the slabs of bias_part[slab][c]: one workgroup per channel, thread t adds the slabs t, t + 256, ...; the 256
+// partial sums are combined by a fixed tree in LDS (the same association on every run)
+__global__ void __launch_bounds__(256)
+k_pw_bias_slabs(const float* __restrict__ part, int nslab, int ld, int C, float* __restrict__ db) {
+  __shared__ float sh[256];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nslab; b += 256) s += part[(size_t)b * ld + c];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) db[c] = sh[0];
 }
 
 // dW[co][ci] = sum over the slabs, in a fixed order: 256 threads = 16 consecutive outputs x 16 slab lanes; lane g sums the
@@ -258,36 +287,6 @@ k_pw_wgrad_reduce(const float* __restrict__ ws, int nslab, int CoP32, int CiP32,
     for (int k = 0; k < 16; ++k) r += part[k][o];
     dW[t] = r;
   }
-}
-
-// db[c] = sum_{n,p} dz[n][c][p] in two fixed-order stages: (channel, image slab) partial sums, then the slabs
-constexpr int PW_BSLAB = 32;
-__global__ void __launch_bounds__(256)
-k_pw_bias_part(const float* __restrict__ dz, int N, int C, int P, float* __restrict__ part_out) {
-  __shared__ float part[256];
-  const int c = blockIdx.x, sl = blockIdx.y;
-  const int per = (N + PW_BSLAB - 1) / PW_BSLAB;
-  const int n0 = sl * per, n1 = min(N, n0 + per);
-  float s = 0.f;
-  for (int n = n0; n < n1; ++n) {
-    const float* row = dz + ((size_t)n * C + c) * P;
-    for (int p = threadIdx.x; p < P; p += 256) s += row[p];
-  }
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) part_out[c * PW_BSLAB + sl] = part[0];
-}
-__global__ void __launch_bounds__(256)
-k_pw_bias_reduce(const float* __restrict__ part, int C, float* __restrict__ db) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int k = 0; k < PW_BSLAB; ++k) s += part[c * PW_BSLAB + k];
-  db[c] = s;
 }
 
 int pw_num_cus() {
@@ -354,7 +353,7 @@ extern "C" size_t fdet_pointwise_wgrad_ws_bytes(int N, int Cin, int Cout, int P)
   const long steps = (long)N * ((P + 15) / 16);
   const long blocks = ((long)CoT * CiT + 3) / 4;
   long nslab = std::max<long>(1, std::min<long>(steps, (8L * 256 + blocks - 1) / blocks));   // ~8 workgroups per CU
-  return ((size_t)nslab * CoT * 32 * CiT * 32 + (size_t)Cout * PW_BSLAB) * sizeof(float);
+  return ((size_t)nslab * CoT * 32 * CiT * 32 + (size_t)nslab * CoT * 32) * sizeof(float);
 }
 
 extern "C" int fdet_pointwise_wgrad_bf16x3(const float* x, const float* dz, float* dW, float* db, void* ws, size_t ws_bytes,
@@ -373,14 +372,11 @@ extern "C" int fdet_pointwise_wgrad_bf16x3(const float* x, const float* dz, floa
   const bool vec = (P % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dz % 16 == 0);
   a.vec_ok = vec;
   dim3 grid((unsigned)blocks, (unsigned)a.nslab);
-  if (vec) hipLaunchKernelGGL(k_pw_wgrad_x3<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_pw_wgrad_x3<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  float* bpart = db ? (float*)ws + (size_t)a.nslab * a.CoT * 32 * a.CiT * 32 : nullptr;     // [nslab][CoT*32]
+  if (vec) hipLaunchKernelGGL(k_pw_wgrad_x3<true>, grid, dim3(256), 0, (hipStream_t)stream, a, bpart);
+  else hipLaunchKernelGGL(k_pw_wgrad_x3<false>, grid, dim3(256), 0, (hipStream_t)stream, a, bpart);
   hipLaunchKernelGGL(k_pw_wgrad_reduce, dim3((Cout * Cin + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
                      a.nslab, a.CoT * 32, a.CiT * 32, Cout, Cin, dW);
-  if (db) {
-    float* bpart = (float*)ws + (size_t)a.nslab * a.CoT * 32 * a.CiT * 32;
-    hipLaunchKernelGGL(k_pw_bias_part, dim3(Cout, PW_BSLAB), dim3(256), 0, (hipStream_t)stream, dz, N, Cout, P, bpart);
-    hipLaunchKernelGGL(k_pw_bias_reduce, dim3((Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)bpart, Cout, db);
-  }
+  if (db) hipLaunchKernelGGL(k_pw_bias_slabs, dim3(Cout), dim3(256), 0, (hipStream_t)stream, (const float*)bpart, a.nslab, a.CoT * 32, Cout, db);
   return check_launch("fdet_pointwise_wgrad_bf16x3");
 }
