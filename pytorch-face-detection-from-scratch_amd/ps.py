@@ -9,6 +9,8 @@ format at every boundary that mirrors a reference interface.
 """
 from __future__ import annotations
 
+import functools
+
 import torch
 
 from ._native import FdetError, check, lib, ptr, stream
@@ -16,6 +18,7 @@ from ._native import FdetError, check, lib, ptr, stream
 F32 = torch.float32
 
 
+@functools.lru_cache(maxsize=None)
 def strips_of(W: int):
     """(S, Ws): column strips of a map of width W (csrc/fdet_ps.h) -- (1, W) for maps of up to 63 columns, (0, 0) when the
     width has no layout (odd and wider than 63)."""
